@@ -1,0 +1,68 @@
+"""ctypes mirror of include/d2d.h (the C ABI of the HIP library).  Field order and types must match
+the header exactly; tests/test_abi.py cross-checks sizes and constants against the header text."""
+import ctypes as C
+
+D2D_ABI_VERSION = 3
+
+UNEXPLORED, OCCUPIED, UNOCCUPIED, DYNAMIC = 0, 1, 2, 3
+SM_WAIT_FOR_GOAL, SM_GOAL_REACHED, SM_PLANNING, SM_EXECUTING = 0, 1, 2, 3
+PLANNER_EXTERNAL, PLANNER_NOMOVE = 0, 1
+
+AF = 6
+A_PX, A_PY, A_VX, A_VY, A_R, A_R2 = range(6)
+DF = 8
+D_X, D_Y, D_YAW, D_VX, D_VY, D_AX, D_AY, D_PAD = range(8)
+CF = 8
+C_STEPS, C_FAIL, C_SM, C_TGT_NEXT, C_NTGT, C_TRACKED, C_BUF_N, C_BUF_TS = range(8)
+F_COLLISION, F_DEADLOCK, F_FREEZING, F_DONE = range(4)
+KF = 20
+
+ST_FSM, ST_AGENTS, ST_RAYCAST, ST_DYNGRID, ST_TRACKER, ST_CONTROL, ST_COLLIDE, ST_OBS = (1 << i for i in range(8))
+ST_PERCEIVE = ST_FSM | ST_AGENTS | ST_RAYCAST | ST_DYNGRID | ST_TRACKER
+ST_ACT = ST_CONTROL | ST_COLLIDE | ST_OBS
+ST_ALL = ST_PERCEIVE | ST_ACT
+
+
+class Cfg(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in
+                ('abi_version', 'B', 'N', 'W', 'H', 'R', 'L', 'T', 'planner_mode', 'kf_enabled',
+                 'reserved0', 'reserved1')] + \
+               [(n, C.c_double) for n in
+                ('dt', 'scale', 'W_px', 'H_px', 'ray_off0', 'ray_dth', 'depth', 'drone_radius', 'yaw_rate',
+                 'max_acc', 'max_steps', 'sigma', 'kf_lo_x', 'kf_hi_x', 'kf_lo_y', 'kf_hi_y')]
+
+
+STATE_FIELDS = ('agents', 'agent_unit', 'dyn_prev', 'gt', 'dmap', 'drone', 'target', 'targets', 'counters',
+                'active', 'kf', 'kf_len', 'action', 'plan_ok', 'wp_valid', 'wp', 'noise', 'hit', 'newly',
+                'flags', 'obs_local', 'obs_yaw')
+
+
+class State(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in STATE_FIELDS]
+
+
+def bind(lib, prefix='d2d_'):
+    """Declare argtypes / restypes of every entry point of include/d2d.h on a loaded CDLL."""
+    P = C.POINTER
+    sig = {
+        'abi_version': (C.c_int, []),
+        'last_error': (C.c_char_p, []),
+        'step': (C.c_int, [P(Cfg), P(State), C.c_void_p]),
+        'perceive': (C.c_int, [P(Cfg), P(State), C.c_void_p]),
+        'act': (C.c_int, [P(Cfg), P(State), C.c_void_p]),
+        'run_stages': (C.c_int, [P(Cfg), P(State), C.c_uint32, C.c_void_p]),
+        'rollout': (C.c_int, [P(Cfg), P(State), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+        'reset': (C.c_int, [P(Cfg), P(State), P(State), C.c_void_p, C.c_void_p]),
+        'tan_array': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    }
+    out = {}
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, prefix + name)   # AttributeError if the symbol is missing: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+        out[name] = fn
+    return out
+
+
+ENTRY_POINTS = ('abi_version', 'last_error', 'step', 'perceive', 'act', 'run_stages', 'rollout', 'reset',
+                'tan_array')

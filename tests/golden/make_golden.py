@@ -1,0 +1,256 @@
+#!/usr/bin/env python3
+"""Golden-vector generator: runs the REAL reference (imported from /root/reference, with
+import-time stubs for the absent gym/pygame/cvxpy) and dumps inputs + expected outputs as
+small .npz fixtures next to this script.
+
+Runs ONLY in the build container (the reference is not present on the GPU box).  The .npz files
+it writes are data (state vectors, grids, flags); no reference source is stored.
+
+Usage:  python tests/golden/make_golden.py            # regenerate every fixture
+"""
+import os, sys, types, json, hashlib
+import numpy as np
+
+REF = '/root/reference'
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def install_stubs():
+    def mk(n):
+        m = types.ModuleType(n); sys.modules[n] = m; return m
+    mk('pygame')
+    cv = mk('cvxpy'); ce = mk('cvxpy.error'); ce.SolverError = Exception; cv.error = ce
+    gym = mk('gym'); gym.__path__ = []
+    gym.Env = type('Env', (), {})
+    gym.logger = type('L', (), {'set_level': staticmethod(lambda x: None)})
+    sp = mk('gym.spaces')
+    sp.Box = type('Box', (), {'__init__': lambda s, low=None, high=None, shape=None, dtype=np.float32:
+                              s.__dict__.update(low=low, high=high, shape=shape, dtype=dtype)})
+    sp.Dict = type('Dict', (), {'__init__': lambda s, d: setattr(s, 'spaces', d)})
+    gym.spaces = sp
+    ge = mk('gym.envs'); ge.__path__ = []
+    gr = mk('gym.envs.registration'); gr.register = lambda **k: None
+    ge.registration = gr; gym.envs = ge
+    sys.path.insert(0, REF); os.chdir(REF)
+    import matplotlib; matplotlib.use('Agg')
+
+
+install_stubs()
+import io, contextlib
+with contextlib.redirect_stdout(io.StringIO()):
+    from utils import Params            # noqa: E402
+    from envs.drone_v2 import Drone2DEnv2   # noqa: E402
+    import yaw_planner                   # noqa: E402
+
+
+def make_params(**kw):
+    p = Params(debug=True, **kw)
+    p.render = False
+    return p
+
+
+def snap_init(env):
+    ag = env.agents
+    N = len(ag)
+    d = dict(
+        agent_pos=np.array([a.position for a in ag], dtype=np.float64).reshape(N, 2),
+        agent_pref=np.array([a.pref_velocity for a in ag], dtype=np.float64).reshape(N, 2),
+        agent_vel=np.array([a.velocity for a in ag], dtype=np.float64).reshape(N, 2),
+        agent_radius=np.array([a.radius for a in ag], dtype=np.float64),
+        agent_group=np.array([a.group_id for a in ag], dtype=np.int64),
+        tracker_radius=np.array([t.radius for t in env.drone.trackers[:max(N, 1)]], dtype=np.float64),
+        gt0=env.map_gt.grid_map.copy(),
+        dyn_idx0=np.array(env.map_gt.dynamic_idx, dtype=np.int32).reshape(-1, 2),
+        obstacles=np.array(env.obstacles, dtype=np.int64).reshape(-1, 3),
+        drone0=np.array([env.drone.x, env.drone.y, env.drone.yaw], dtype=np.float64),
+    )
+    return d
+
+
+def run_trace(params, T, actions=None, policy=None, teleport=None, stop_on_done=True,
+              mutate=None):
+    """Step the reference env T times (or until done) recording every input and output."""
+    env = Drone2DEnv2(params)
+    pol = None
+    if policy is not None:
+        pol = getattr(yaw_planner, policy)
+        pol.__init__(pol, params)
+    init = snap_init(env)
+    N = len(env.agents)
+    rec = {k: [] for k in ['action', 'agent_pos', 'agent_pref', 'gt', 'dmap', 'hit', 'newly',
+                           'active_pre', 'active_post', 'drone', 'vel', 'sm', 'fail', 'flags', 'done',
+                           'obs_local', 'obs_yaw', 'plan_ok', 'wp_valid', 'wp', 'target', 'tele',
+                           'kf_mu', 'kf_sigma', 'kf_len', 'buf_len', 'traj_len', 'steps']}
+    # wrap planner.plan to capture its result as seen by step_pos
+    plan_cap = {}
+    orig_plan = env.planner.plan
+
+    def plan_wrap(drone, dt):
+        ok = orig_plan(drone, dt)
+        tr = env.planner.trajectory
+        plan_cap['ok'] = bool(ok)
+        plan_cap['n'] = len(tr)
+        if len(tr) > 0:
+            plan_cap['wp'] = np.concatenate([np.asarray(tr.positions[0], dtype=np.float64).ravel(),
+                                             np.asarray(tr.velocities[0], dtype=np.float64).ravel(),
+                                             np.asarray(tr.accelerations[0], dtype=np.float64).ravel()])
+        else:
+            plan_cap['wp'] = np.zeros(6)
+        plan_cap['target'] = np.asarray(env.planner.target, dtype=np.float64).copy()
+        return ok
+    env.planner.plan = plan_wrap
+
+    for t in range(T):
+        if pol is not None:
+            a = pol.plan(pol, env.info)
+            a = 0.0 if a is None else float(a)
+        else:
+            a = float(actions[t])
+        if teleport is not None:
+            env.drone.x, env.drone.y = teleport[t]
+            rec['tele'].append(np.array(teleport[t], dtype=np.float64))
+        if mutate is not None:
+            mutate(env, t)
+        active_pre = np.array([tr.active for tr in env.drone.trackers[:N]], dtype=np.uint8)
+        tracked_before = env.tracked_agent
+        obs, rew, done, info = env.step(a)
+        hit = np.zeros(N, dtype=np.uint8)
+        for ray in env.drone.rays:
+            hit |= ray['hit_list'].numpy().astype(np.uint8)
+        rec['action'].append(a)
+        rec['agent_pos'].append(np.array([ag.position for ag in env.agents], dtype=np.float64).reshape(N, 2))
+        rec['agent_pref'].append(np.array([ag.pref_velocity for ag in env.agents], dtype=np.float64).reshape(N, 2))
+        rec['gt'].append(env.map_gt.grid_map.copy())
+        rec['dmap'].append(env.drone.map.grid_map.copy())
+        rec['hit'].append(hit)
+        rec['newly'].append(env.tracked_agent - tracked_before)
+        rec['active_pre'].append(active_pre)
+        rec['active_post'].append(np.array([tr.active for tr in env.drone.trackers[:N]], dtype=np.uint8))
+        rec['drone'].append(np.array([env.drone.x, env.drone.y, float(np.asarray(env.drone.yaw).ravel()[0])], dtype=np.float64))
+        rec['vel'].append(np.concatenate([np.asarray(env.drone.velocity, dtype=np.float64).ravel(),
+                                          np.asarray(env.drone.acceleration, dtype=np.float64).ravel()]))
+        rec['sm'].append(env.state_machine)
+        rec['fail'].append(env.fail_count)
+        rec['flags'].append(np.array([info['collision_flag'], info['dead_lock_flag'], info['freezing_flag']], dtype=np.uint8))
+        rec['done'].append(bool(done))
+        rec['obs_local'].append(obs['local_map'][0].copy())
+        rec['obs_yaw'].append(obs['yaw_angle'].copy())
+        rec['plan_ok'].append(plan_cap['ok'])
+        rec['wp_valid'].append(plan_cap['n'] > 0)
+        rec['wp'].append(plan_cap['wp'])
+        rec['target'].append(plan_cap['target'])
+        rec['kf_mu'].append(np.array([tr.mu_upds[-1][:, 0] for tr in env.drone.trackers[:N]], dtype=np.float64).reshape(N, 4))
+        rec['kf_sigma'].append(np.array([np.asarray(tr.Sigma_upds[-1], dtype=np.float64) for tr in env.drone.trackers[:N]]).reshape(N, 4, 4))
+        rec['kf_len'].append(np.array([len(tr.ts) for tr in env.drone.trackers[:N]], dtype=np.int32))
+        rec['buf_len'].append(len(info['tracker_buffer']))
+        rec['traj_len'].append(len(env.planner.trajectory))
+        rec['steps'].append(env.steps)
+        if done and stop_on_done:
+            break
+    out = dict(init)
+    for k, v in rec.items():
+        if len(v):
+            out['t_' + k] = np.array(v)
+    pd = {k: v for k, v in vars(params).items()}
+    out['params_json'] = np.array(json.dumps(pd, default=lambda o: list(o) if hasattr(o, '__iter__') else str(o)))
+    return out
+
+
+def save(name, d):
+    path = os.path.join(OUT, name + '.npz')
+    np.savez_compressed(path, **d)
+    print(f'{name}: {os.path.getsize(path)/1024:.1f} KiB, steps={len(d.get("t_action", []))}')
+
+
+def main():
+    rng = np.random.RandomState(12345)
+
+    # --- A. NoMove closed loop, BASELINE config-1/2 parameters, constant action (SURVEY section 4 KAT)
+    p = make_params(planner='NoMove', agent_number=10, agent_radius=15, agent_max_speed=20, map_id=1)
+    save('nomove_n10_const', run_trace(p, 200, actions=[0.5] * 200))
+
+    # --- B. NoMove, random actions, several seeds (short)
+    for mid in (0, 2, 3, 7):
+        p = make_params(planner='NoMove', agent_number=10, agent_radius=15, agent_max_speed=20, map_id=mid)
+        save(f'nomove_n10_rand_map{mid}', run_trace(p, 60, actions=rng.uniform(-1, 1, 60)))
+
+    # --- C. structured yaw (multiples of 4 deg => exact 45-degree rays) with teleports over integer positions
+    p = make_params(planner='NoMove', agent_number=10, agent_radius=15, agent_max_speed=20, map_id=4)
+    T = 120
+    tele = [(int(rng.randint(21, 479)), int(rng.randint(21, 479))) for _ in range(T)]
+    acts = rng.choice([-1.0, -0.5, 0.0, 0.5, 1.0, 0.225], size=T)
+    save('nomove_teleport_structured', run_trace(p, T, actions=acts, teleport=tele, stop_on_done=False))
+
+    # --- D. survivability-style sweep cell (drone pinned, NoControl => 360 deg view), runs past done
+    p = make_params(planner='NoMove', gaze_method='NoControl', agent_number=20, agent_radius=10,
+                    agent_max_speed=40, map_id=5)
+    p.drone_view_range = 360
+    T = 80
+    save('surv_pinned_360', run_trace(p, T, actions=[0.0] * T, teleport=[(200, 260)] * T, stop_on_done=False))
+
+    # --- E. static maps => extra radius-5 agents (obstacle_map: +14, shaped: +46, random_map_0: +122)
+    p = make_params(planner='NoMove', agent_number=10, agent_radius=15, agent_max_speed=20, map_id=1,
+                    static_map='maps/obstacle_map.npy')
+    save('nomove_obstacle_map', run_trace(p, 60, actions=rng.uniform(-1, 1, 60), stop_on_done=False))
+    p = make_params(planner='NoMove', agent_number=10, agent_radius=10, agent_max_speed=40, map_id=2,
+                    static_map='maps/shaped_obstacle_map.npy')
+    save('nomove_shaped_map', run_trace(p, 40, actions=rng.uniform(-1, 1, 40), stop_on_done=False))
+    p = make_params(planner='NoMove', agent_number=50, agent_radius=10, agent_max_speed=40, map_id=0,
+                    static_map='maps/random_map_0.npy')
+    save('nomove_random_map_n172', run_trace(p, 25, actions=rng.uniform(-1, 1, 25), stop_on_done=False))
+
+    # --- F. random radii (agent_radius=-1), pillars (static circles), slow agents (stuck rotation branch)
+    p = make_params(planner='NoMove', agent_number=15, agent_radius=-1, agent_max_speed=30, map_id=9, pillar_number=4)
+    save('nomove_pillars_randr', run_trace(p, 80, actions=rng.uniform(-1, 1, 80), stop_on_done=False))
+    p = make_params(planner='NoMove', agent_number=8, agent_radius=12, agent_max_speed=4, map_id=3)
+    save('nomove_slow_agents', run_trace(p, 80, actions=rng.uniform(-1, 1, 80), stop_on_done=False))
+
+    # --- G. non-default geometry: 1000x800 px map (100x80 cells, R=100 rays > one wave), depth 120, FOV 120
+    p = make_params(planner='NoMove', agent_number=30, agent_radius=12, agent_max_speed=40, map_id=6,
+                    map_size=[1000, 800], drone_view_depth=120, drone_view_range=120,
+                    init_pos=[300, 400], target_list=[[900, 700]])
+    save('nomove_big_map', run_trace(p, 40, actions=rng.uniform(-1, 1, 40), stop_on_done=False))
+
+    # --- H. README config: Oxford gaze + Primitive planner (planner heads + actions recorded as inputs)
+    p = make_params(gaze_method='Oxford', planner='Primitive', agent_number=10, agent_max_speed=20,
+                    agent_radius=15, drone_max_speed=40, map_id=1)
+    save('readme_oxford_primitive', run_trace(p, 800, policy='Oxford'))
+    # LookAhead + Primitive on a harder map: exercises brake / replanning / collisions
+    for mid in (0, 3):
+        p = make_params(gaze_method='LookAhead', planner='Primitive', agent_number=30, agent_max_speed=40,
+                        agent_radius=10, drone_max_speed=40, map_id=mid)
+        save(f'lookahead_primitive_n30_map{mid}', run_trace(p, 800, policy='LookAhead'))
+
+    # --- I. init-only fixtures (host init restatement): many seeds / settings
+    inits = {}
+    cfgs = []
+    for mid in range(12):
+        cfgs.append(dict(agent_number=10, agent_radius=15, agent_max_speed=20, map_id=mid))
+    for (n, r, v) in [(10, 5, 20), (20, 10, 40), (30, 15, 60), (30, 5, 60)]:
+        cfgs.append(dict(agent_number=n, agent_radius=r, agent_max_speed=v, map_id=11))
+    cfgs.append(dict(agent_number=12, agent_radius=-1, agent_max_speed=25, map_id=13, pillar_number=5))
+    cfgs.append(dict(agent_number=10, agent_radius=15, agent_max_speed=20, map_id=1, static_map='maps/obstacle_map.npy'))
+    cfgs.append(dict(agent_number=5, agent_radius=8, agent_max_speed=20, map_id=2, static_map='maps/shaped_obstacle_map.npy'))
+    cfgs.append(dict(agent_number=50, agent_radius=10, agent_max_speed=40, map_id=0, static_map='maps/random_map_0.npy'))
+    for i, c in enumerate(cfgs):
+        p = make_params(planner='NoMove', **c)
+        env = Drone2DEnv2(p)
+        s = snap_init(env)
+        for k, v in s.items():
+            inits[f'c{i}_{k}'] = v
+        inits[f'c{i}_cfg'] = np.array(json.dumps(c))
+    inits['n_cfg'] = np.array(len(cfgs))
+    save('init_cases', inits)
+
+    # --- J. static map label grids as (x, y, label) triplets (data for the package's maps/ directory)
+    maps = {}
+    for m in ['empty_map', 'obstacle_map', 'shaped_obstacle_map', 'random_map_0']:
+        a = np.load(os.path.join(REF, 'maps', m + '.npy'))
+        xs, ys = np.nonzero(a)
+        maps[m + '_shape'] = np.array(a.shape)
+        maps[m + '_xyl'] = np.stack([xs, ys, a[xs, ys]], axis=1).astype(np.int32).reshape(-1, 3)
+    save('static_maps', maps)
+
+
+if __name__ == '__main__':
+    main()
