@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""bench.py — env-steps/s of the batched Drone2D step on MI355X (BASELINE.json metric).
+
+  python bench.py --gpus 1 --steps 200 --warmup 20
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+Workload (N=1): BASELINE.json configs[1] — 4096 batched envs x 10 agents, agent_radius=15, 50x50 grid,
+50 rays, env i = the reference world for map_id 1+i.  A "step" = one fused Drone2DEnv2.step over the
+whole batch (one d2d_step launch).  Gaze actions are fixed-seed U(-1,1) and the planner result is a
+synthetic resident waypoint stream (the device follows it exactly as it follows a Primitive trajectory
+head; Oxford/Primitive themselves are host plugins in the reference and not part of this hot path —
+SURVEY.md 8(d) C2).  Inputs are resident in HBM before the timed region.  N>1: every rank steps its own
+shard of 4096 envs (weak scaling, no per-step collective; one RCCL all_gather of episode statistics).
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ALGO_BYTES_PER_ENV_STEP = 3844      # N=10, c=9, R=50, S=10, L=33
+HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def synth_plan(torch, T, B, W_px, H_px, seed, device):
+    """Resident synthetic planner heads [T, B, 6]: each drone follows its own smooth closed curve through the
+    map interior at <= 40 px/s, positions rounded like Primitive's np.around heads (traj_planner.py:121)."""
+    g = torch.Generator().manual_seed(seed)
+    ph = torch.rand(B, 4, generator=g, dtype=torch.float64) * 6.283185307179586
+    fr = 0.5 + torch.rand(B, 2, generator=g, dtype=torch.float64)
+    t = torch.arange(T, dtype=torch.float64).view(T, 1) * 0.1
+    cx, cy = W_px / 2.0, H_px / 2.0
+    ax, ay = W_px / 2.0 - 45.0, H_px / 2.0 - 45.0
+    w = 0.08
+    x = cx + ax * torch.sin(w * fr[:, 0] * t + ph[:, 0])
+    y = cy + ay * torch.sin(w * fr[:, 1] * t + ph[:, 1])
+    vx = ax * w * fr[:, 0] * torch.cos(w * fr[:, 0] * t + ph[:, 0])
+    vy = ay * w * fr[:, 1] * torch.cos(w * fr[:, 1] * t + ph[:, 1])
+    wp = torch.stack([x.round(), y.round(), vx, vy, torch.zeros_like(x), torch.zeros_like(x)], dim=2)
+    return wp.contiguous().to(device)
+
+
+def cpu_baseline(pkg, params, budget_s=12.0):
+    """The CPU oracle (oracle/, a scalar C port of the reference step) timed on this box's host cores on a
+    bounded sample of the same workload: 256 envs of the same family, NoMove, same action stream."""
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import numpy as np
+    from oracle_lib import OracleBackend
+    from drone2d_amd import vec_env
+    ob = OracleBackend()
+    cores = os.cpu_count() or 1
+    B = 256
+    env = vec_env.VecDrone2DEnv(params, B, backend=ob, planner='NoMove')
+    rng = np.random.RandomState(0)
+    out = {}
+    for label, threads in (('1', 1), ('all', cores)):
+        ob.lib.d2d_oracle_set_threads(threads)
+        env.reset()
+        n = 0
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < budget_s / 2:
+            env.step(rng.uniform(-1, 1, B))
+            n += 1
+        dt = time.perf_counter() - t0
+        out[label] = B * n / dt
+    ob.lib.d2d_oracle_set_threads(1)
+    return {'value': out['all'], 'unit': 'env-steps/s', 'cores': cores, 'kind': 'port',
+            'single_core_value': out['1'],
+            'sample': f'oracle/d2d_oracle.c on {B} envs x 10 agents (same family as the GPU workload, NoMove), '
+                      f'~{budget_s / 2:.0f} s on 1 thread and ~{budget_s / 2:.0f} s on {cores} OpenMP threads; '
+                      'reference Python itself: 268 env-steps/s on 1 core (BASELINE.md)'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=500)
+    ap.add_argument('--warmup', type=int, default=50)
+    ap.add_argument('--envs', type=int, default=4096, help='envs per GPU')
+    ap.add_argument('--agents', type=int, default=10)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--mode', default='launch', choices=['launch', 'graph'],
+                    help='launch: one d2d_step launch per step; graph: the K launches captured in one hipGraph')
+    args = ap.parse_args()
+
+    import torch
+    import drone2d_amd as pkg
+    from drone2d_amd import vec_env, _abi as A
+
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        torch.cuda.set_device(local)
+        dist.init_process_group('nccl', device_id=torch.device(f'cuda:{local}'))
+    device = f'cuda:{local}'
+    torch.cuda.set_device(local)
+
+    B, K, Wm = args.envs, args.steps, args.warmup
+    params = pkg.Params(planner='Primitive', gaze_method='Oxford', agent_number=args.agents, agent_radius=15,
+                        agent_max_speed=20, drone_max_speed=40, map_id=1)
+    env = vec_env.VecDrone2DEnv(params, B, device=device, planner='external', env_offset=rank * B,
+                                workers=min(8, os.cpu_count() or 1))
+    T = K + Wm
+    g = torch.Generator().manual_seed(1234 + rank)
+    actions = (torch.rand(T, B, generator=g, dtype=torch.float64) * 2 - 1).to(device)
+    wp = synth_plan(torch, T, B, params.map_size[0], params.map_size[1], 99 + rank, device)
+    env.state.plan_ok.fill_(1)
+    env.state.wp_valid.fill_(1)
+    st = env.state.struct()
+    cfg = env.cfg
+    be = env.backend
+    fn_step = be.fn['step']
+    a_ptr, w_ptr = actions.data_ptr(), wp.data_ptr()
+    stream = torch.cuda.current_stream(device)
+    sp = C.c_void_p(stream.cuda_stream)
+
+    def launch(t):
+        st.action = a_ptr + t * B * 8
+        st.wp = w_ptr + t * B * 6 * 8
+        rc = fn_step(C.byref(cfg), C.byref(st), sp)
+        if rc:
+            raise RuntimeError(be.fn['last_error']().decode())
+
+    for t in range(Wm):
+        launch(t)
+    torch.cuda.synchronize()
+
+    graph = None
+    if args.mode == 'graph':
+        graph = torch.cuda.CUDAGraph()
+        cs = torch.cuda.Stream(device)
+        with torch.cuda.graph(graph, stream=cs):
+            sp = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+            for t in range(Wm, T):
+                launch(t)
+        torch.cuda.synchronize()
+
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record(stream)
+    if graph is not None:
+        graph.replay()
+    else:
+        for t in range(Wm, T):
+            launch(t)
+    e1.record(stream)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    gpu_ms = e0.elapsed_time(e1)
+
+    # episode statistics: the only exchange of the path (RCCL all_gather over xGMI), once per run
+    stats = env.episode_stats()
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+        allstats = [torch.empty_like(stats) for _ in range(world)]
+        dist.all_gather(allstats, stats)
+        stats = torch.cat(allstats)
+
+    if rank == 0:
+        value = world * B * K / elapsed
+        launch_us = gpu_ms * 1e3 / K                       # HIP-event time per launch on the launch stream
+        achieved = ALGO_BYTES_PER_ENV_STEP * B / (launch_us * 1e-6) / 1e9
+        traffic = None
+        pj = os.path.join(ROOT, 'profiles', 'pmc_latest.json')
+        if os.path.isfile(pj):
+            try:
+                traffic = json.load(open(pj)).get('hbm_bytes_per_launch')
+            except Exception:
+                traffic = None
+        line = {
+            'metric': 'env-steps/sec (batched) at 10 agents, map_id=1', 'value': value, 'unit': 'env-steps/s',
+            'n_gpus': world, 'steps': K, 'warmup': Wm, 'ms_per_step': elapsed * 1e3 / K,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': f'configs[1]: {B} batched envs per GPU x {args.agents} agents, agent_radius=15, '
+                                   '50x50 uint8 grid, 50 rays, map_id=1+env',
+                       'envs_per_gpu': B, 'agents': env.N, 'launch_mode': args.mode,
+                       'gaze': 'fixed-seed U(-1,1) actions resident in HBM (Oxford is a host plugin)',
+                       'planner': 'synthetic resident waypoint heads, followed as Primitive heads are '
+                                  '(Primitive is a host plugin)',
+                       'kalman_trackers': 'on device', 'auto_reset': False},
+            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'kernel': 'k_stages (fused step)',
+                         'launch_us': launch_us, 'algo_bytes_per_env_step': ALGO_BYTES_PER_ENV_STEP},
+            'episode_stats': {'envs': int(stats.shape[0]), 'dynamic_collisions': int(stats[:, 3].sum()),
+                              'mean_cells_discovered': float(stats[:, 6].double().mean())},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            line['cpu_baseline'] = cpu_baseline(pkg, params)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

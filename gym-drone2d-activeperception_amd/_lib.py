@@ -1,0 +1,72 @@
+"""Loader of the HIP library (csrc/libd2d_hip.so).  There is NO CPU fallback: if the library is missing
+or its ABI does not match, importing the backend raises."""
+import ctypes as C
+import os
+
+from . import _abi as A
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libd2d_hip.so')
+
+
+class D2DError(RuntimeError):
+    pass
+
+
+def load_library(path=LIB_PATH):
+    if not os.path.isfile(path):
+        raise D2DError(f'{path} not found: build it with gym-drone2d-activeperception_amd/csrc/build.sh '
+                       '(or __graft_entry__.build()); there is no CPU fallback')
+    lib = C.CDLL(path)
+    fn = A.bind(lib, prefix='d2d_')
+    v = fn['abi_version']()
+    if v != A.D2D_ABI_VERSION:
+        raise D2DError(f'libd2d_hip.so ABI {v} != expected {A.D2D_ABI_VERSION}: rebuild')
+    return lib, fn
+
+
+class HipBackend:
+    """Thin call surface over the C ABI; launches go to torch's current HIP stream of `device`."""
+    name = 'hip'
+
+    def __init__(self, device='cuda:0'):
+        import torch
+        if not torch.cuda.is_available():
+            raise D2DError('HipBackend needs a GPU (torch.cuda.is_available() is False)')
+        self.torch = torch
+        self.device = torch.device(device)
+        self.lib, self.fn = load_library()
+
+    def _stream(self):
+        return C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise D2DError(f'd2d error {rc}: {self.fn["last_error"]().decode()}')
+
+    def run_stages(self, cfg, st, stages):
+        self._chk(self.fn['run_stages'](C.byref(cfg), C.byref(st), stages, self._stream()))
+
+    def step(self, cfg, st):
+        self._chk(self.fn['step'](C.byref(cfg), C.byref(st), self._stream()))
+
+    def perceive(self, cfg, st):
+        self._chk(self.fn['perceive'](C.byref(cfg), C.byref(st), self._stream()))
+
+    def act(self, cfg, st):
+        self._chk(self.fn['act'](C.byref(cfg), C.byref(st), self._stream()))
+
+    def rollout(self, cfg, st, nsteps, actions, pin=None, coll_out=None):
+        self._chk(self.fn['rollout'](C.byref(cfg), C.byref(st), nsteps, actions.data_ptr(),
+                                     None if pin is None else pin.data_ptr(),
+                                     None if coll_out is None else coll_out.data_ptr(), self._stream()))
+
+    def reset(self, cfg, st, init, mask=None):
+        self._chk(self.fn['reset'](C.byref(cfg), C.byref(st), C.byref(init),
+                                   None if mask is None else mask.data_ptr(), self._stream()))
+
+    def tan_array(self, x, out):
+        self._chk(self.fn['tan_array'](x.data_ptr(), out.data_ptr(), x.numel(), self._stream()))
+
+    def sync(self):
+        self.torch.cuda.synchronize(self.device)

@@ -1,0 +1,138 @@
+"""VecDrone2DEnv — B independent Drone2D worlds stepped in lock-step on one MI355X.
+
+Batched counterpart of the reference's `Drone2DEnv2` (envs/drone_v2.py:10-261): the same step semantics
+per env, state resident in HBM, one fused HIP launch per step.  Env `i` of the batch is the world the
+reference builds for `params.map_id + i` (+ `env_offset` of the shard), so results do not depend on how
+the batch is sharded across GPUs.
+
+Planner modes
+  'NoMove'    traj_planner.py:68-76 runs on the device (one launch per step)
+  'external'  the caller supplies plan_ok / wp_valid / wp each step (host planner plugin between
+              `perceive()` and `act()`, or replayed plans with the fused `step()`)
+"""
+import numpy as np
+import torch
+
+from . import _abi as A
+from . import host_init
+from .params import with_defaults
+from .state import BatchState
+
+
+def _build_world(args):
+    params, map_id = args
+    p = with_defaults(params)
+    p.map_id = map_id
+    return host_init.init_world(p)
+
+
+class VecDrone2DEnv:
+    def __init__(self, params, num_envs, device='cuda:0', planner=None, env_offset=0, backend=None,
+                 kf_enabled=True, workers=0, worlds=None):
+        self.params = with_defaults(params)
+        self.num_envs = int(num_envs)
+        self.env_offset = int(env_offset)
+        planner = planner if planner is not None else self.params.planner
+        self.planner_mode = A.PLANNER_NOMOVE if planner == 'NoMove' else A.PLANNER_EXTERNAL
+        if backend is None:
+            from ._lib import HipBackend       # raises if the HIP library or the GPU is missing
+            backend = HipBackend(device)
+        self.backend = backend
+        self.device = torch.device(backend.device)
+        if worlds is None:
+            jobs = [(self.params, self.params.map_id + self.env_offset + i) for i in range(self.num_envs)]
+            if workers and self.num_envs >= 64:
+                import multiprocessing as mp
+                with mp.get_context('fork').Pool(workers) as pool:
+                    worlds = pool.map(_build_world, jobs, chunksize=max(1, self.num_envs // (workers * 8)))
+            else:
+                worlds = [_build_world(j) for j in jobs]
+        N = worlds[0]['N'] if worlds else 0
+        T = worlds[0]['T'] if worlds else 1
+        if any(w['N'] != N for w in worlds):
+            raise ValueError('all envs of a batch must have the same number of agents')
+        self.cfg = host_init.derive_cfg(self.params, B=self.num_envs, N=N, T=T,
+                                        planner_mode=self.planner_mode, kf_enabled=kf_enabled)
+        self.state = BatchState(self.cfg, self.device)
+        self.state.load_worlds(worlds)
+        self.tracker_radius = torch.from_numpy(np.stack([w['tracker_radius'] for w in worlds])) if worlds else None
+        self.init_state = self.state.clone_world()
+        self._st = self.state.struct()
+        self._init_st = self.init_state.struct()
+        self.reward = torch.zeros(self.num_envs, dtype=torch.float32, device=self.device)   # drone_v2.py:257
+
+    # ------------------------------------------------------------------ gym-like surface (batched)
+    @property
+    def N(self):
+        return self.cfg.N
+
+    def reset(self, mask=None):
+        """envs/drone_v2.py:259-261: back to the seeded initial world (all envs, or those in `mask`)."""
+        if mask is not None:
+            mask = mask.to(device=self.device, dtype=torch.uint8).contiguous()
+        self.backend.reset(self.cfg, self._st, self._init_st, mask)
+        return {}
+
+    def _set_action(self, actions):
+        a = torch.as_tensor(actions, dtype=torch.float64)
+        self.state.action.copy_(a.reshape(-1).expand(self.num_envs) if a.numel() == 1 else a.reshape(self.num_envs),
+                                non_blocking=True)
+
+    def set_plan(self, plan_ok, wp_valid, wp):
+        """External planner result for this step (traj_planner.py Planner.plan + trajectory head)."""
+        self.state.plan_ok.copy_(torch.as_tensor(plan_ok, dtype=torch.uint8).reshape(self.num_envs))
+        self.state.wp_valid.copy_(torch.as_tensor(wp_valid, dtype=torch.uint8).reshape(self.num_envs))
+        self.state.wp.copy_(torch.as_tensor(wp, dtype=torch.float64).reshape(self.num_envs, 6))
+
+    def step(self, actions):
+        """One fused Drone2DEnv2.step for every env.  Returns (obs, reward, done, info) of tensors."""
+        self._set_action(actions)
+        self.backend.step(self.cfg, self._st)
+        return self._result()
+
+    def perceive(self):
+        """First half of step() (lines 153-187); a host planner plugin runs after this."""
+        self.backend.perceive(self.cfg, self._st)
+
+    def act(self, actions):
+        """Second half of step() (lines 198-255)."""
+        self._set_action(actions)
+        self.backend.act(self.cfg, self._st)
+        return self._result()
+
+    def rollout(self, actions, pin=None, collisions=False):
+        """`actions`: [T, B] gaze actions; T fused steps in one launch (survivability-style sweeps,
+        glob_survivability_calculator.py:31-37).  `pin`: [B, 2] drone position forced before each step."""
+        actions = torch.as_tensor(actions, dtype=torch.float64, device=self.device).contiguous()
+        T = actions.shape[0]
+        assert actions.shape == (T, self.num_envs)
+        if pin is not None:
+            pin = torch.as_tensor(pin, dtype=torch.float64, device=self.device).contiguous()
+        coll = torch.zeros((T, self.num_envs), dtype=torch.uint8, device=self.device) if collisions else None
+        self.backend.rollout(self.cfg, self._st, T, actions, pin, coll)
+        return coll
+
+    def _result(self):
+        s = self.state
+        obs = {'local_map': s.obs_local.unsqueeze(1), 'swep_map': s.obs_local.unsqueeze(1),   # drone_v2.py:251-255
+               'yaw_angle': s.obs_yaw.unsqueeze(1)}
+        done = s.flags[:, A.F_DONE].bool()
+        info = {'collision_flag': s.flags[:, A.F_COLLISION], 'dead_lock_flag': s.flags[:, A.F_DEADLOCK],
+                'freezing_flag': s.flags[:, A.F_FREEZING], 'state_machine': s.counters[:, A.C_SM],
+                'flight_time': s.counters[:, A.C_STEPS].double() * self.cfg.dt,
+                'tracked_agent': s.counters[:, A.C_TRACKED], 'newly_tracked': s.newly, 'hit': s.hit}
+        return obs, self.reward, done, info
+
+    def sync(self):
+        self.backend.sync()
+
+    # ------------------------------------------------------------------ episode statistics (CSV row, experiment.py:73-103)
+    def episode_stats(self):
+        """Per-env int64 [B, 8]: steps, success, static collision, dynamic collision, freezing, dead lock,
+        grid discovered, agents tracked."""
+        s = self.state
+        c = s.counters.long()
+        f = s.flags.long()
+        disc = (s.dmap != 0).flatten(1).sum(1)
+        return torch.stack([c[:, A.C_STEPS], (c[:, A.C_SM] == A.SM_GOAL_REACHED).long(), (f[:, 0] == 1).long(),
+                            (f[:, 0] == 2).long(), f[:, 2], f[:, 1], disc, c[:, A.C_BUF_N]], dim=1)

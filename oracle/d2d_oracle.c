@@ -27,6 +27,10 @@ static int fail(int code, const char *msg) {
   return code;
 }
 
+static int g_threads = 1;
+/* number of host threads run_stages spreads envs over (default 1 = scalar) */
+void d2d_oracle_set_threads(int n) { g_threads = n > 0 ? n : 1; }
+
 int d2d_oracle_abi_version(void) { return D2D_ABI_VERSION; }
 const char *d2d_oracle_last_error(void) { return g_err; }
 
@@ -457,6 +461,8 @@ int d2d_oracle_run_stages(const d2d_cfg *c, const d2d_state *s, uint32_t stages,
   (void)stream;
   int rc = check(c, s);
   if (rc) return rc;
+  /* envs are independent: the cpu_baseline leg of bench.py may spread them over host threads */
+#pragma omp parallel for schedule(static) num_threads(g_threads > 0 ? g_threads : 1)
   for (int e = 0; e < c->B; ++e) {
     env_view v = view(c, s, e);
     if (stages & D2D_ST_FSM) st_fsm(&v);

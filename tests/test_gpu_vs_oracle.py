@@ -1,0 +1,138 @@
+"""HIP path vs the CPU oracle on seeded random batches, step for step (run with -m gpu).
+Every field of the state is compared bit for bit (integers and fp64 alike)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+FIELDS = ('agents', 'dyn_prev', 'gt', 'dmap', 'drone', 'target', 'counters', 'active', 'kf', 'kf_len', 'hit',
+          'newly', 'flags', 'obs_local', 'obs_yaw')
+
+
+def _pair(pkg, hip, oracle, B, **pk):
+    from drone2d_amd import vec_env
+    planner = pk.pop('planner', 'NoMove')
+    p = pkg.Params(planner=planner, **pk)
+    ref = vec_env.VecDrone2DEnv(p, B, backend=oracle)
+    worlds = None
+    dev = vec_env.VecDrone2DEnv(p, B, backend=hip, worlds=_worlds(ref))
+    return dev, ref
+
+
+def _worlds(env):
+    """Re-use the host-built worlds of `env` (saves building them twice)."""
+    s = env.init_state
+    out = []
+    for e in range(env.num_envs):
+        out.append(dict(agents=s.agents[e].numpy(), agent_unit=s.agent_unit[e].numpy(), dyn_prev=s.dyn_prev[e].numpy(),
+                        gt=s.gt[e].numpy(), dmap=s.dmap[e].numpy(), drone=s.drone[e].numpy(),
+                        target=s.target[e].numpy(), targets=s.targets[e].numpy(), counters=s.counters[e].numpy(),
+                        tracker_radius=env.tracker_radius[e].numpy(), N=env.cfg.N, T=env.cfg.T))
+    return out
+
+
+def _assert_same(dev, ref, tag):
+    dev.sync()
+    for name in FIELDS:
+        a, b = dev.state.t[name].cpu(), ref.state.t[name]
+        if not torch.equal(a, b):
+            bad = (a != b).nonzero()
+            raise AssertionError(f'{tag}: field {name} differs at {bad[:5].tolist()} ({len(bad)} elements)')
+
+
+CASES = [
+    dict(B=37, T=40, agent_number=10, agent_radius=15, agent_max_speed=20, map_id=100),
+    dict(B=9, T=25, agent_number=30, agent_radius=-1, agent_max_speed=60, map_id=7, pillar_number=3),
+    dict(B=5, T=12, agent_number=50, agent_radius=10, agent_max_speed=40, map_id=0, static_map='maps/random_map_0.npy'),
+    dict(B=6, T=20, agent_number=70, agent_radius=6, agent_max_speed=40, map_id=3, map_size=[1000, 800],
+         drone_view_depth=120, drone_view_range=200, init_pos=[420, 400], target_list=[[900, 700], [100, 100]]),
+    dict(B=8, T=30, agent_number=6, agent_radius=12, agent_max_speed=4, map_id=11),
+    dict(B=4, T=15, agent_number=0, agent_radius=10, agent_max_speed=20, map_id=2),
+]
+
+
+@pytest.mark.parametrize('case', CASES, ids=lambda c: f"N{c['agent_number']}_B{c['B']}")
+def test_fused_step_matches_oracle(pkg, hip, oracle, case):
+    case = dict(case)
+    B, T = case.pop('B'), case.pop('T')
+    dev, ref = _pair(pkg, hip, oracle, B, **case)
+    rng = np.random.RandomState(B * 1000 + T)
+    for t in range(T):
+        a = rng.uniform(-1, 1, B)
+        if t % 7 == 3:   # teleport some drones (external mutation API, validation_speed.py:135-138)
+            xy = torch.from_numpy(np.stack([rng.randint(15, dev.cfg.W_px - 15, B), rng.randint(15, dev.cfg.H_px - 15, B)], 1).astype(np.float64))
+            dev.state.drone[:, :2] = xy.to(dev.device)
+            ref.state.drone[:, :2] = xy
+        dev.step(a)
+        ref.step(a)
+        _assert_same(dev, ref, f'step {t + 1}')
+
+
+def test_external_planner_inputs_and_split_halves(pkg, hip, oracle):
+    """Random plan_ok / waypoint inputs (brake + follow branches), perceive()+act() on the device vs
+    the fused oracle step."""
+    B, T = 16, 40
+    dev, ref = _pair(pkg, hip, oracle, B, planner='Primitive', agent_number=12, agent_radius=10, agent_max_speed=30, map_id=50)
+    rng = np.random.RandomState(3)
+    for t in range(T):
+        a = rng.uniform(-1, 1, B)
+        ok = rng.rand(B) < 0.7
+        valid = ok & (rng.rand(B) < 0.8)
+        wp = np.concatenate([rng.uniform(20, 480, (B, 2)).round() + rng.choice([0.0, 0.5], (B, 2)),
+                             rng.uniform(-40, 40, (B, 2)), np.zeros((B, 2))], axis=1)
+        for env in (dev, ref):
+            env.set_plan(ok, valid, wp)
+        dev.perceive()
+        dev.act(a)
+        ref.step(a)
+        _assert_same(dev, ref, f'step {t + 1}')
+
+
+def test_rollout_and_reset_on_device(pkg, hip, oracle):
+    B, T = 21, 30
+    dev, ref = _pair(pkg, hip, oracle, B, agent_number=20, agent_radius=10, agent_max_speed=40, map_id=5)
+    rng = np.random.RandomState(9)
+    acts = rng.uniform(-1, 1, (T, B))
+    pin = np.stack([rng.randint(30, 470, B), rng.randint(30, 470, B)], 1).astype(np.float64)
+    cd = dev.rollout(acts, pin=pin, collisions=True)
+    cr = ref.rollout(acts, pin=pin, collisions=True)
+    dev.sync()
+    assert torch.equal(cd.cpu(), cr)
+    _assert_same(dev, ref, 'after rollout')
+    mask = torch.from_numpy((rng.rand(B) < 0.5).astype(np.uint8))
+    dev.reset(mask)
+    ref.reset(mask)
+    _assert_same(dev, ref, 'after masked reset')
+    dev.step(acts[0]); ref.step(acts[0])
+    _assert_same(dev, ref, 'step after reset')
+
+
+def test_full_size_properties(pkg, hip):
+    """BASELINE config 2 size (4096 envs x 10 agents): size-independent properties on the device alone:
+    (i) a batch of identical worlds stays identical, (ii) wall cells of gt never change, explored cells only
+    grow, every explored cell agrees with gt's wall/free classification, (iii) reset is idempotent."""
+    from drone2d_amd import vec_env, host_init
+    p = pkg.Params(planner='NoMove', agent_number=10, agent_radius=15, agent_max_speed=20, map_id=1)
+    w = host_init.init_world(pkg.with_defaults(p))
+    B = 4096
+    env = vec_env.VecDrone2DEnv(p, B, backend=hip, worlds=[w] * B)
+    gt0 = env.state.gt.clone()
+    prev_explored = torch.zeros_like(env.state.dmap, dtype=torch.bool)
+    rng = np.random.RandomState(0)
+    for t in range(20):
+        env.step(float(rng.uniform(-1, 1)))
+        s = env.state
+        for name in ('agents', 'gt', 'dmap', 'drone', 'flags', 'obs_local', 'hit'):
+            x = s.t[name]
+            assert bool((x == x[0:1]).all()), f'{name} diverged across identical envs at step {t + 1}'
+        assert torch.equal(s.gt == 1, gt0 == 1)
+        explored = s.dmap != 0
+        assert bool((prev_explored <= explored).all())
+        assert bool(((s.dmap == 1) <= (s.gt == 1)).all()) and bool(((s.dmap == 2) <= (s.gt != 1)).all())
+        prev_explored = explored
+    env.reset()
+    a = {k: v.clone() for k, v in env.state.t.items()}
+    env.reset()
+    for k in ('agents', 'gt', 'dmap', 'drone', 'counters'):
+        assert torch.equal(a[k], env.state.t[k])

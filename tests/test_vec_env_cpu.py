@@ -1,0 +1,78 @@
+"""Host logic of VecDrone2DEnv, exercised on CPU with the oracle standing in for the HIP library
+(test-only injection; the product default is HipBackend and raises without a GPU)."""
+import numpy as np
+import pytest
+import torch
+
+
+def _mk(pkg, oracle, B, **kw):
+    from drone2d_amd import vec_env
+    p = pkg.Params(planner='NoMove', agent_number=10, agent_radius=15, agent_max_speed=20, map_id=kw.pop('map_id', 0))
+    return vec_env.VecDrone2DEnv(p, B, backend=oracle, **kw)
+
+
+def test_default_backend_fails_loudly_without_gpu(pkg):
+    from drone2d_amd import vec_env, _lib
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    with pytest.raises(_lib.D2DError):
+        vec_env.VecDrone2DEnv(pkg.Params(planner='NoMove'), 2)
+
+
+def test_batch_envs_are_independent_and_seeded_by_global_id(pkg, oracle):
+    """env i of a batch == a single env built with map_id + i; shards (env_offset) agree too."""
+    rng = np.random.RandomState(0)
+    acts = rng.uniform(-1, 1, (30, 6))
+    big = _mk(pkg, oracle, 6)
+    shard = _mk(pkg, oracle, 3, env_offset=3)
+    singles = [_mk(pkg, oracle, 1, map_id=i) for i in range(6)]
+    for t in range(30):
+        big.step(acts[t])
+        shard.step(acts[t, 3:])
+        for i, s in enumerate(singles):
+            s.step(acts[t, i:i + 1])
+    for name in ('agents', 'gt', 'dmap', 'drone', 'counters', 'flags', 'hit', 'obs_local', 'kf', 'active'):
+        for i, s in enumerate(singles):
+            assert torch.equal(big.state.t[name][i], s.state.t[name][0]), name
+        assert torch.equal(big.state.t[name][3:], shard.state.t[name]), name
+
+
+def test_reset_restores_the_seeded_world(pkg, oracle):
+    env = _mk(pkg, oracle, 4)
+    snap = {k: v.clone() for k, v in env.state.t.items()}
+    for t in range(12):
+        env.step(np.full(4, 0.3))
+    mask = torch.tensor([1, 0, 1, 0], dtype=torch.uint8)
+    moved = {k: v.clone() for k, v in env.state.t.items()}
+    env.reset(mask)
+    for name in ('agents', 'gt', 'dmap', 'drone', 'counters', 'kf', 'kf_len', 'active', 'dyn_prev', 'target'):
+        assert torch.equal(env.state.t[name][0], snap[name][0]) and torch.equal(env.state.t[name][2], snap[name][2]), name
+        assert torch.equal(env.state.t[name][1], moved[name][1]) and torch.equal(env.state.t[name][3], moved[name][3]), name
+    env.reset()
+    for name in ('agents', 'gt', 'dmap', 'drone', 'counters'):
+        assert torch.equal(env.state.t[name], snap[name]), name
+
+
+def test_rollout_equals_repeated_steps(pkg, oracle):
+    rng = np.random.RandomState(1)
+    acts = rng.uniform(-1, 1, (25, 5))
+    a, b = _mk(pkg, oracle, 5), _mk(pkg, oracle, 5)
+    pin = np.tile(np.array([[200.0, 260.0]]), (5, 1))
+    coll = a.rollout(acts, pin=pin, collisions=True)
+    for t in range(25):
+        b.state.drone[:, 0] = 200.0
+        b.state.drone[:, 1] = 260.0
+        _, _, _, info = b.step(acts[t])
+        assert torch.equal(coll[t], info['collision_flag'])
+    for name in ('agents', 'gt', 'dmap', 'drone', 'counters', 'flags', 'obs_local'):
+        assert torch.equal(a.state.t[name], b.state.t[name]), name
+
+
+def test_step_outputs_have_reference_shapes(pkg, oracle):
+    env = _mk(pkg, oracle, 3)
+    obs, rew, done, info = env.step(0.5)
+    assert obs['local_map'].shape == (3, 1, 33, 33) and obs['local_map'].dtype == torch.uint8
+    assert obs['swep_map'].data_ptr() == obs['local_map'].data_ptr()      # drone_v2.py:252-253: same map twice
+    assert obs['yaw_angle'].shape == (3, 1) and obs['yaw_angle'].dtype == torch.float32
+    assert float(obs['yaw_angle'][0, 0]) == 274.0 and rew.shape == (3,) and not done.any()
+    assert env.episode_stats().shape == (3, 8)
