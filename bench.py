@@ -86,6 +86,9 @@ def main():
     ap.add_argument('--envs', type=int, default=4096, help='envs per GPU')
     ap.add_argument('--agents', type=int, default=10)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--workers', type=int, default=min(8, os.cpu_count() or 1),
+                    help='host processes building the worlds (forked BEFORE the GPU is touched; 0 = in-process, '
+                         'use 0 under rocprofv3)')
     ap.add_argument('--mode', default='launch', choices=['launch', 'graph'],
                     help='launch: one d2d_step launch per step; graph: the K launches captured in one hipGraph')
     args = ap.parse_args()
@@ -97,6 +100,11 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    B, K, Wm = args.envs, args.steps, args.warmup
+    params = pkg.Params(planner='Primitive', gaze_method='Oxford', agent_number=args.agents, agent_radius=15,
+                        agent_max_speed=20, drone_max_speed=40, map_id=1)
+    # host world construction (the reference's __init__, seeded per global env id) before any GPU call
+    worlds = vec_env.build_worlds(params, B, env_offset=rank * B, workers=args.workers)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -105,11 +113,7 @@ def main():
     device = f'cuda:{local}'
     torch.cuda.set_device(local)
 
-    B, K, Wm = args.envs, args.steps, args.warmup
-    params = pkg.Params(planner='Primitive', gaze_method='Oxford', agent_number=args.agents, agent_radius=15,
-                        agent_max_speed=20, drone_max_speed=40, map_id=1)
-    env = vec_env.VecDrone2DEnv(params, B, device=device, planner='external', env_offset=rank * B,
-                                workers=min(8, os.cpu_count() or 1))
+    env = vec_env.VecDrone2DEnv(params, B, device=device, planner='external', env_offset=rank * B, worlds=worlds)
     T = K + Wm
     g = torch.Generator().manual_seed(1234 + rank)
     actions = (torch.rand(T, B, generator=g, dtype=torch.float64) * 2 - 1).to(device)

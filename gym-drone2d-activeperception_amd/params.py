@@ -56,12 +56,14 @@ class Params:
         return cls(**vars(a))
 
 
+class ParamsView:
+    """Plain attribute bag returned by with_defaults()."""
+
+
 def with_defaults(params):
     """Attribute-style view of `params` that falls back to the reference defaults for missing fields
     (script/train.py builds an EasyDict without planner / map_id / max_flight_time ...)."""
-    class _View:
-        pass
-    v = _View()
+    v = ParamsView()
     d = Params()
     for k, val in vars(d).items():
         setattr(v, k, val)

@@ -36,6 +36,7 @@ class BatchState:
         for name, (shape, dt) in _spec(cfg.B, cfg.N, cfg.W, cfg.H, cfg.L, cfg.T).items():
             self.t[name] = torch.zeros(shape, dtype=dt, device=self.device)
         self.noise = None
+        self._dummy = torch.zeros(64, dtype=torch.float64, device=self.device)   # target of empty fields (N == 0)
         self._kf_defaults()
 
     def _kf_defaults(self):
@@ -64,7 +65,7 @@ class BatchState:
     def clone_world(self):
         """Snapshot of the world fields (reset source)."""
         snap = BatchState.__new__(BatchState)
-        snap.cfg, snap.device, snap.noise = self.cfg, self.device, None
+        snap.cfg, snap.device, snap.noise, snap._dummy = self.cfg, self.device, None, self._dummy
         snap.t = {k: (v.clone() if k in WORLD_FIELDS else v) for k, v in self.t.items()}
         return snap
 
@@ -76,12 +77,14 @@ class BatchState:
             elif name in ('plan_ok', 'wp_valid', 'wp') and not use_planner_inputs:
                 setattr(s, name, None)
             else:
-                setattr(s, name, self.t[name].data_ptr())
+                t = self.t[name]
+                setattr(s, name, t.data_ptr() if t.numel() else self._dummy.data_ptr())
         return s
 
     def to(self, device):
         out = BatchState.__new__(BatchState)
         out.cfg, out.device = self.cfg, torch.device(device)
+        out._dummy = self._dummy.to(device)
         out.t = {k: v.to(device) for k, v in self.t.items()}
         out.noise = None if self.noise is None else self.noise.to(device)
         return out

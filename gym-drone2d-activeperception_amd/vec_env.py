@@ -26,9 +26,22 @@ def _build_world(args):
     return host_init.init_world(p)
 
 
+def build_worlds(params, num_envs, env_offset=0, workers=0):
+    """Host construction of `num_envs` worlds: env i is the reference world for map_id + env_offset + i.
+    With `workers` > 0 the (pure Python, GPU-free) construction is spread over forked processes; call
+    this before the process touches the GPU."""
+    p = with_defaults(params)
+    jobs = [(p, p.map_id + env_offset + i) for i in range(num_envs)]
+    if workers and num_envs >= 64:
+        import multiprocessing as mp
+        with mp.get_context('fork').Pool(workers) as pool:
+            return pool.map(_build_world, jobs, chunksize=max(1, num_envs // (workers * 8)))
+    return [_build_world(j) for j in jobs]
+
+
 class VecDrone2DEnv:
     def __init__(self, params, num_envs, device='cuda:0', planner=None, env_offset=0, backend=None,
-                 kf_enabled=True, workers=0, worlds=None):
+                 kf_enabled=True, worlds=None):
         self.params = with_defaults(params)
         self.num_envs = int(num_envs)
         self.env_offset = int(env_offset)
@@ -40,13 +53,7 @@ class VecDrone2DEnv:
         self.backend = backend
         self.device = torch.device(backend.device)
         if worlds is None:
-            jobs = [(self.params, self.params.map_id + self.env_offset + i) for i in range(self.num_envs)]
-            if workers and self.num_envs >= 64:
-                import multiprocessing as mp
-                with mp.get_context('fork').Pool(workers) as pool:
-                    worlds = pool.map(_build_world, jobs, chunksize=max(1, self.num_envs // (workers * 8)))
-            else:
-                worlds = [_build_world(j) for j in jobs]
+            worlds = build_worlds(self.params, self.num_envs, self.env_offset, workers=0)
         N = worlds[0]['N'] if worlds else 0
         T = worlds[0]['T'] if worlds else 1
         if any(w['N'] != N for w in worlds):
