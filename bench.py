@@ -47,20 +47,36 @@ def synth_plan(torch, T, B, W_px, H_px, seed, device):
     return wp.contiguous().to(device)
 
 
-def cpu_baseline(pkg, params, budget_s=12.0):
+def host_cores():
+    """Cores this process may really use: affinity mask, capped by the cgroup CPU quota if there is one."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        q, per = open('/sys/fs/cgroup/cpu.max').read().split()
+        if q != 'max':
+            n = max(1, min(n, int(float(q) / float(per))))
+    except Exception:
+        pass
+    return n
+
+
+def cpu_baseline(pkg, params, budget_s=14.0):
     """The CPU oracle (oracle/, a scalar C port of the reference step) timed on this box's host cores on a
-    bounded sample of the same workload: 256 envs of the same family, NoMove, same action stream."""
+    bounded sample of the same workload: 2048 envs of the same family, NoMove, same kind of action stream.
+    Timed on 1 thread and on min(cores, 32) OpenMP threads over envs; the faster is reported with the thread
+    count actually used."""
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     import numpy as np
     from oracle_lib import OracleBackend
     from drone2d_amd import vec_env
     ob = OracleBackend()
-    cores = os.cpu_count() or 1
-    B = 256
-    env = vec_env.VecDrone2DEnv(params, B, backend=ob, planner='NoMove')
+    avail = host_cores()
+    many = max(1, min(avail, 32))
+    B = 2048
+    worlds = vec_env.build_worlds(params, 64, workers=0)
+    env = vec_env.VecDrone2DEnv(params, B, backend=ob, planner='NoMove', worlds=[worlds[i % 64] for i in range(B)])
     rng = np.random.RandomState(0)
     out = {}
-    for label, threads in (('1', 1), ('all', cores)):
+    for threads in sorted({1, many}):
         ob.lib.d2d_oracle_set_threads(threads)
         env.reset()
         n = 0
@@ -68,14 +84,14 @@ def cpu_baseline(pkg, params, budget_s=12.0):
         while time.perf_counter() - t0 < budget_s / 2:
             env.step(rng.uniform(-1, 1, B))
             n += 1
-        dt = time.perf_counter() - t0
-        out[label] = B * n / dt
+        out[threads] = B * n / (time.perf_counter() - t0)
     ob.lib.d2d_oracle_set_threads(1)
-    return {'value': out['all'], 'unit': 'env-steps/s', 'cores': cores, 'kind': 'port',
-            'single_core_value': out['1'],
-            'sample': f'oracle/d2d_oracle.c on {B} envs x 10 agents (same family as the GPU workload, NoMove), '
-                      f'~{budget_s / 2:.0f} s on 1 thread and ~{budget_s / 2:.0f} s on {cores} OpenMP threads; '
-                      'reference Python itself: 268 env-steps/s on 1 core (BASELINE.md)'}
+    best = max(out, key=out.get)
+    return {'value': out[best], 'unit': 'env-steps/s', 'cores': best, 'kind': 'port',
+            'single_core_value': out[1], 'host_cores_available': avail,
+            'sample': f'oracle/d2d_oracle.c, {B} envs x 10 agents (64 distinct seeded worlds of the GPU workload\'s '
+                      f'family, NoMove), ~{budget_s / 2:.0f} s per thread count {sorted(out)}; '
+                      'reference Python itself: 268 env-steps/s on 1 core (BASELINE.md, build container)'}
 
 
 def main():
