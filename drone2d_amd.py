@@ -4,5 +4,10 @@ import importlib
 import os
 import sys
 
+_REAL = 'gym-drone2d-activeperception_amd'
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-sys.modules[__name__] = importlib.import_module('gym-drone2d-activeperception_amd')
+_pkg = importlib.import_module(_REAL)
+sys.modules[__name__] = _pkg
+for _k, _v in list(sys.modules.items()):          # submodules loaded by the package's own __init__
+    if _k.startswith(_REAL + '.'):
+        sys.modules.setdefault(__name__ + _k[len(_REAL):], _v)

@@ -1,0 +1,67 @@
+"""Multi-process path on CPU: world_size 2 over gloo.  Each rank steps its shard (oracle backend standing in
+for the HIP library), the shards gather episode statistics, and the result equals the single-process
+run env for env."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TOTAL, STEPS = 7, 25      # odd on purpose: shards of 4 and 3 envs
+
+
+def _actions():
+    return np.random.RandomState(42).uniform(-1, 1, (STEPS, TOTAL))
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port))
+    import drone2d_amd as pkg
+    from drone2d_amd import dist as d2dist
+    from oracle_lib import OracleBackend
+    d2dist.init_process_group('gloo')
+    p = pkg.Params(planner='NoMove', agent_number=10, agent_radius=15, agent_max_speed=40, map_id=3)
+    env = d2dist.make_shard(p, TOTAL, device='cpu', backend=OracleBackend())
+    lo, hi = d2dist.shard_range(TOTAL, rank, world)
+    assert env.num_envs == hi - lo and env.env_offset == lo
+    acts = _actions()
+    for t in range(STEPS):
+        env.step(acts[t, lo:hi])
+    stats = d2dist.gather_episode_stats(env, TOTAL)
+    q.put((rank, stats.numpy(), env.state.drone.numpy().copy()))
+    import torch.distributed as dist
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_shards_equal_one_process(pkg, oracle):
+    from drone2d_amd import vec_env, dist as d2dist
+    assert d2dist.shard_range(7, 0, 2) == (0, 4) and d2dist.shard_range(7, 1, 2) == (4, 7)
+    assert [d2dist.shard_range(262144, r, 8) for r in (0, 7)] == [(0, 32768), (229376, 262144)]
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29600 + os.getpid() % 200
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    got = {}
+    for _ in range(2):
+        r, stats, drone = q.get(timeout=180)
+        got[r] = (stats, drone)
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    p = pkg.Params(planner='NoMove', agent_number=10, agent_radius=15, agent_max_speed=40, map_id=3)
+    ref = vec_env.VecDrone2DEnv(p, TOTAL, backend=oracle)
+    acts = _actions()
+    for t in range(STEPS):
+        ref.step(acts[t])
+    want = ref.episode_stats().numpy()
+    assert np.array_equal(got[0][0], want) and np.array_equal(got[1][0], want)      # every rank holds the full table
+    assert np.array_equal(np.concatenate([got[0][1], got[1][1]]), ref.state.drone.numpy())
