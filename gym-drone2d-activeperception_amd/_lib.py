@@ -6,7 +6,7 @@ import os
 from . import _abi as A
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libd2d_hip.so')
+LIB_PATH = os.environ.get('D2D_LIB') or os.path.join(_HERE, 'csrc', 'libd2d_hip.so')   # D2D_LIB: A/B builds
 
 
 class D2DError(RuntimeError):

@@ -6,5 +6,5 @@ cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 $HIPCC --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-fast-math -fPIC -shared \
   -Wall -Wno-unused-function ${D2D_EXTRA_FLAGS:-} \
-  -o libd2d_hip.so d2d_hip.hip
-echo "built $(pwd)/libd2d_hip.so"
+  -o ${D2D_OUT:-libd2d_hip.so} d2d_hip.hip
+echo "built $(pwd)/${D2D_OUT:-libd2d_hip.so}"
