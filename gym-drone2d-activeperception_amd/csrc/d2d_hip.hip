@@ -6,9 +6,15 @@
 //   agents / trackers / dynamic grid : lane = agent  (N > 64 loops)
 //   raycast                          : lane = ray    (R > 64 loops); agents that can possibly be
 //                                      hit are compacted into LDS with __ballot + popcount, the
-//                                      ground-truth window the rays can reach is staged in LDS
+//                                      ground-truth window the rays can reach is an LDS tile
 //   collision                        : lane = probe / agent, __any / __ballot reduction
-//   observation                      : lanes sweep the L x L crop, rows contiguous in memory
+//   observation                      : an LDS tile of the drone's map that the rays patch in place
+// Memory schedule of one env-step (what the kernel is bound by is the chain of dependent HBM round
+// trips, ~2.5k cycles each, so there are exactly two plus the final stores):
+//   batch 1  everything whose address does not depend on data: pose, counters, inputs, agents, trackers
+//   batch 2  everything addressed by batch-1 data: ground-truth window and map crop (LDS-DMA, no VGPRs),
+//            dynamic-grid cells, collision probes -- issued together, tan / candidate work runs meanwhile
+//   stores   agents, drone map, grid, trackers, flags, observation: fire and forget
 // There is no dense contraction on this path, hence no MFMA.  Arithmetic is fp64 in the reference's
 // own operation order (compiled with -ffp-contract=off; the few fused multiply-adds are the ones the
 // reference's runtime performs: libm tan, OpenBLAS dgemv), which is what makes the integer outputs
@@ -104,49 +110,85 @@ struct FastDiv {
 };
 
 struct LdsView {
-  double *ax, *ay, *ar, *ar2;  // all agents of the env after this step's move   [ncap]
-  double *cx, *cy, *cr2, *crr;  // compacted ray candidates (centre, r^2, r)      [ncap]
-  int *cidx;                   // candidate -> agent index                        [ncap]
-  int *ncx, *ncy, *nu;         // new dynamic block of every agent (cell, half)   [ncap]
-  unsigned int *bm;            // bitmap of cells covered by some agent's new block [bmw]
-  unsigned char *hit;          // per-agent hit flag (OR over rays)               [ncap]
-  unsigned char *gtw;          // staged ground-truth window                      [ws * ws]
+  double *ax, *ay, *ar, *ar2;    // all agents of the env after this step's move   [ncap]
+  double *cx, *cy, *cr2, *crr;   // compacted ray candidates (centre, r^2, r)      [ncap]
+  double *kf;                    // tracker state staged in batch 1, plane-major   [20][ncap] (if g.kf_lds)
+  int *cidx;                     // candidate -> agent index                        [ncap]
+  int *ncx, *ncy, *nu;           // new dynamic block of every agent (cell, half)   [ncap]
+  int *pcx, *pcy, *pu;           // block written last time (dyn_prev)              [ncap]
+  int *klen;                     // len(tracker.ts)                                 [ncap]
+  unsigned int *bm;              // bitmap of cells covered by some agent's new block [bmw]
+  unsigned int *gtw;             // ground-truth window tile, dwords                [ws][wdw]
+  unsigned int *dmt;             // drone-map crop tile, dwords                     [L][ldw]
+  unsigned char *hit, *act;      // per-agent hit flag (OR over rays), tracker.active [ncap]
 };
 
 struct Geom {
   int ncap;   // N rounded up to a multiple of 4
   int reach;  // cells a ray can travel from the drone cell
   int ws;     // window edge = 2 * reach + 1
+  int wdw;    // dwords per window row (any byte alignment of the row start)
+  int ldw;    // dwords per crop row
   int smax;   // samples after which every ray has stopped: sample k is >= k * ss from the drone
   int klo;    // samples 0..klo are < depth from the drone whatever the slope (k * ss * sqrt(2) < depth)
   int bmw;    // dwords of the per-env cell bitmap kept in LDS (0: grid too large, loop over agents instead)
+  int kf_lds; // tracker state staged in LDS (fits the 64 KB workgroup budget)
   int wave_bytes;
 };
 
-__host__ __device__ inline Geom make_geom(const d2d_cfg &c) {
+// `wpb`: waves (envs) per workgroup; the LDS budget of a workgroup is 64 KB
+__host__ __device__ inline Geom make_geom(const d2d_cfg &c, int wpb) {
   Geom g;
   g.ncap = (c.N + 3) & ~3;
   if (g.ncap < 4) g.ncap = 4;
   g.reach = (int)((c.depth + 1.5 * (c.scale - 1.0)) / c.scale) + 2;
   g.ws = 2 * g.reach + 1;
+  g.wdw = (g.ws + 6) / 4;
+  g.ldw = (c.L + 6) / 4;
   const double ss = c.scale - 1.0;
   g.smax = (int)(c.depth / ss) + 2;
-  g.klo = (int)(c.depth / (ss * 1.4142136)) - ((c.depth / (ss * 1.4142136)) == (double)(int)(c.depth / (ss * 1.4142136)) ? 1 : 0);
+  const double kl = c.depth / (ss * 1.4142136);
+  g.klo = (int)kl - ((kl == (double)(int)kl) ? 1 : 0);
   if (g.klo < -1) g.klo = -1;
   g.bmw = (c.W * c.H + 31) / 32;
   if (g.bmw > 2048) g.bmw = 0;  // 8 KB per wave at most (256 x 256 cells)
-  g.wave_bytes = (81 * g.ncap + 4 * g.bmw + g.ws * g.ws + 15) & ~15;
+  const int base = 64 * g.ncap + 32 * g.ncap + 4 * g.bmw + 4 * g.ws * g.wdw + 4 * c.L * g.ldw + 2 * g.ncap;
+  g.kf_lds = (c.kf_enabled && ((base + 160 * g.ncap + 15) & ~15) * wpb <= 64 * 1024) ? 1 : 0;
+  g.wave_bytes = (base + (g.kf_lds ? 160 * g.ncap : 0) + 15) & ~15;
   return g;
+}
+
+__device__ __forceinline__ LdsView carve(char *base, const Geom &g, int Lm) {
+  LdsView L;
+  L.ax = (double *)base;
+  L.ay = L.ax + g.ncap;
+  L.ar = L.ay + g.ncap;
+  L.ar2 = L.ar + g.ncap;
+  L.cx = L.ar2 + g.ncap;
+  L.cy = L.cx + g.ncap;
+  L.cr2 = L.cy + g.ncap;
+  L.crr = L.cr2 + g.ncap;
+  L.kf = L.crr + g.ncap;
+  L.cidx = (int *)(L.kf + (g.kf_lds ? 20 * g.ncap : 0));
+  L.ncx = L.cidx + g.ncap;
+  L.ncy = L.ncx + g.ncap;
+  L.nu = L.ncy + g.ncap;
+  L.pcx = L.nu + g.ncap;
+  L.pcy = L.pcx + g.ncap;
+  L.pu = L.pcy + g.ncap;
+  L.klen = L.pu + g.ncap;
+  L.bm = (unsigned int *)(L.klen + g.ncap);
+  L.gtw = L.bm + g.bmw;
+  L.dmt = L.gtw + g.ws * g.wdw;
+  L.hit = (unsigned char *)(L.dmt + Lm * g.ldw);
+  L.act = L.hit + g.ncap;
+  return L;
 }
 
 struct EnvRegs {  // lane-uniform per-env scalars carried in registers across the fused stages
   double x, y, yaw, vx, vy, ax, ay;
   double tx, ty;
   int steps, fail, sm, tnext, ntgt, tracked, bufn, bufts;
-};
-
-struct Consts {  // per-launch derived constants
-  double inv_scale;
 };
 
 // Python / numpy `int(v // s)` for integer-valued s > 0: the exact mathematical floor.  floor(v * (1/s))
@@ -157,6 +199,71 @@ __device__ __forceinline__ int cell_fast(double v, double s, double inv_s) {
   if (r < 0.0) q -= 1.0;
   else if (r >= s) q += 1.0;
   return (int)q;
+}
+
+// floor(v / s) for 0 < v < 2^24 and integer s >= 2: floor(v / s) == floor(floor(v) / s), and floor(v) fits
+// an int, so the rest is 24-bit integer work (full-rate VALU) instead of fp64.
+struct CellDiv {
+  float inv;
+  int s;
+  __device__ __forceinline__ explicit CellDiv(double scale) : inv(1.0f / (float)scale), s((int)scale) {}
+  __device__ __forceinline__ int operator()(double v) const {
+    const int vi = (int)v;  // truncation == floor for v >= 0
+    int q = (int)((float)vi * inv);
+    const int r = vi - q * s;
+    q += (r >= s) ? 1 : 0;
+    q -= (r < 0) ? 1 : 0;
+    return q;
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+// LDS tiles of a uint8 grid, filled by LDS-DMA (global_load_lds_dword: no VGPRs, asynchronous)
+// ------------------------------------------------------------------------------------------------
+// A tile covers `rows` x `cols` cells from cell (i0, j0).  Row r is kept as `ndw` dwords starting at the
+// 4-byte-aligned address at or below its first cell, so cell (r, q) sits at LDS byte r*ndw*4 + off(r) + q
+// with off(r) = (address of cell (i0 + r, j0)) & 3.  Cells outside the grid are never consulted (the
+// callers mask them), so rows / dwords outside it are simply not loaded.
+struct Tile {
+  long long a0;  // address of cell (i0, j0) (may lie outside the grid when i0 / j0 are negative)
+  int i0, j0, rows, cols, ndw, H;
+  __device__ __forceinline__ int off(int r) const { return (int)((a0 + (long long)r * H) & 3); }
+  __device__ __forceinline__ int byte_index(int r, int q) const { return r * ndw * 4 + off(r) + q; }
+};
+
+__device__ __forceinline__ Tile make_tile(const unsigned char *grid, int H, int i0, int j0, int rows, int cols, int ndw) {
+  Tile t;
+  t.a0 = (long long)(uintptr_t)grid + (long long)i0 * H + j0;
+  t.i0 = i0; t.j0 = j0; t.rows = rows; t.cols = cols; t.ndw = ndw; t.H = H;
+  return t;
+}
+
+// issue the DMA of a tile (the caller waits with vmcnt(0) before reading it)
+__device__ __forceinline__ void tile_load(const Tile &t, unsigned int *lds, int W, int lane, const unsigned char *lo,
+                                          const unsigned char *hi) {
+  const FastDiv fd(t.ndw);
+  const int n = t.rows * t.ndw;
+  for (int base = 0; base < n; base += WAVE) {
+    const int idx = base + lane;
+    int r, d;
+    fd.divmod(idx, r, d);
+    const int i = t.i0 + r;
+    const long long row0 = t.a0 + (long long)r * t.H;          // address of cell (i, j0)
+    const long long a = (row0 & ~3ll) + 4ll * d;               // this dword
+    const int jfirst = t.j0 + (int)(a - row0);                 // column of its first byte
+    const bool want = idx < n && i >= 0 && i < W && jfirst + 3 >= 0 && jfirst < t.H && jfirst < t.j0 + t.cols;
+    const unsigned char *ap = (const unsigned char *)(uintptr_t)a;
+    if (want && ap >= lo && ap + 4 <= hi) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)ap,
+                                       (__attribute__((address_space(3))) void *)(lds + base), 4, 0, 0);
+    } else if (want) {  // dword straddles the end of the whole tensor: byte by byte (first / last env only)
+      const __attribute__((address_space(1))) unsigned char *gp = (const __attribute__((address_space(1))) unsigned char *)ap;
+      unsigned int w = 0;
+      for (int b = 0; b < 4; ++b)
+        if (ap + b >= lo && ap + b < hi) w |= (unsigned int)gp[b] << (8 * b);
+      lds[idx] = w;
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -178,19 +285,92 @@ __device__ __forceinline__ void st_fsm(const d2d_cfg &c, const d2d_state &s, int
   }
 }
 
-// envs/drone_v2.py:176-179 + utils.py:472-493; lane = agent.  With `move` false the agents are only
-// staged into LDS (a launch that does not contain the AGENTS stage).
-__device__ __forceinline__ void st_agents(const d2d_cfg &c, const d2d_state &s, int e, int lane, const LdsView &L,
-                                          const Consts &k_, bool move) {
+// Planner result + gaze action of this step, loaded in batch 1
+struct StepIn {
+  double action;
+  double wp[6];
+  bool ok, has_wp;
+};
+
+__device__ __forceinline__ void load_inputs(const d2d_cfg &c, const d2d_state &s, int e, double action, bool control,
+                                            StepIn &in) {
+  in.action = action;
+  in.ok = true;
+  in.has_wp = false;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) in.wp[i] = 0.0;
+  if (control && c.planner_mode != D2D_PLANNER_NOMOVE) {
+    in.ok = s.plan_ok[e] != 0;
+    in.has_wp = s.wp_valid[e] != 0;
+    const double *wp = s.wp + (size_t)e * 6;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) in.wp[i] = wp[i];
+  }
+}
+
+// envs/drone_v2.py:197-214 with utils.py:733-743, 755-762 (lane-uniform scalar work)
+__device__ __forceinline__ void st_control(const d2d_cfg &c, const StepIn &in, EnvRegs &r) {
+  if (c.planner_mode == D2D_PLANNER_NOMOVE) {
+    r.tx = -1.0;  // traj_planner.py:72
+    r.ty = -1.0;
+  }
+  if (!in.ok) {
+    const double n = sqrt(r.vx * r.vx + r.vy * r.vy);
+    if (n <= c.max_acc * c.dt) {
+      r.vx = 0.0;
+      r.vy = 0.0;
+    } else {
+      r.vx = r.vx - r.vx / n * c.max_acc * c.dt;
+      r.vy = r.vy - r.vy / n * c.max_acc * c.dt;
+      r.x += r.vx * c.dt;
+      r.y += r.vy * c.dt;
+    }
+    r.sm = D2D_SM_PLANNING;
+    r.fail += 1;
+  } else {
+    r.sm = D2D_SM_EXECUTING;
+    r.fail = 0;
+  }
+  if (in.has_wp) {
+    r.ax = in.wp[4];
+    r.ay = in.wp[5];
+    r.vx = in.wp[2];
+    r.vy = in.wp[3];
+    r.x = rint(in.wp[0]);  // round(): half to even
+    r.y = rint(in.wp[1]);
+  }
+  r.yaw = py_mod360(r.yaw + in.action * c.yaw_rate * c.dt);
+}
+
+// envs/drone_v2.py:176-179 + utils.py:472-493; lane = agent.  Batch-1 loads of everything per-agent
+// (agent planes, unit, previous dynamic block, tracker active / len / state) are issued together; the
+// moved agents and the staged tracker data land in LDS for the later stages.  With `move` false the
+// agents are only staged (a launch without the AGENTS stage).
+__device__ __forceinline__ void st_agents(const d2d_cfg &c, const d2d_state &s, int e, int lane, const Geom &g,
+                                          const LdsView &L, double inv_scale, bool move, bool want_trk) {
   const int N = c.N;
-  double *ag = s.agents + (size_t)e * D2D_AF * N;
+  double *__restrict__ ag = s.agents + (size_t)e * D2D_AF * N;
+  const int *__restrict__ prev = s.dyn_prev + (size_t)e * N * 3;
   const double cs = 0x1.bb67ae8584cabp-1, sn = 0x1.fffffffffffffp-2;  // cos(pi/6), sin(pi/6)
   for (int k = lane; k < N; k += WAVE) {
     double px = ag[D2D_A_PX * N + k], py = ag[D2D_A_PY * N + k];
+    const double velx = ag[D2D_A_VX * N + k], vely = ag[D2D_A_VY * N + k];
     const double rr = ag[D2D_A_R * N + k], r2 = ag[D2D_A_R2 * N + k];
     const int u = s.agent_unit[(size_t)e * N + k];
+    const int p0 = prev[3 * k], p1 = prev[3 * k + 1], p2 = prev[3 * k + 2];
+    const unsigned char act = s.active[(size_t)e * N + k];
+    int klen = 1;
+    double kf[D2D_KF];
+    const bool stage_kf = want_trk && c.kf_enabled;
+    if (stage_kf) {
+      klen = s.kf_len[(size_t)e * N + k];
+      if (g.kf_lds) {
+        const double *__restrict__ gk = s.kf + ((size_t)e * N + k) * D2D_KF;
+#pragma unroll
+        for (int i = 0; i < D2D_KF; ++i) kf[i] = gk[i];
+      }
+    }
     if (move) {
-      const double velx = ag[D2D_A_VX * N + k], vely = ag[D2D_A_VY * N + k];
       const double nx = px + velx * c.dt, ny = py + vely * c.dt;
       bool aliased = true;
       double pvx = velx, pvy = vely;
@@ -218,9 +398,18 @@ __device__ __forceinline__ void st_agents(const d2d_cfg &c, const d2d_state &s, 
     L.ay[k] = py;
     L.ar[k] = rr;
     L.ar2[k] = r2;
-    L.ncx[k] = cell_fast(px, c.scale, k_.inv_scale);
-    L.ncy[k] = cell_fast(py, c.scale, k_.inv_scale);
+    L.ncx[k] = cell_fast(px, c.scale, inv_scale);
+    L.ncy[k] = cell_fast(py, c.scale, inv_scale);
     L.nu[k] = u;
+    L.pcx[k] = p0;
+    L.pcy[k] = p1;
+    L.pu[k] = p2;
+    L.act[k] = act;
+    L.klen[k] = klen;
+    if (stage_kf && g.kf_lds) {
+#pragma unroll
+      for (int i = 0; i < D2D_KF; ++i) L.kf[i * g.ncap + k] = kf[i];
+    }
   }
 }
 
@@ -232,61 +421,10 @@ __device__ __forceinline__ double positive_angle(double a) {
   return a;
 }
 
-// floor(v / s) for 0 < v < 2^31 and integer s >= 2: floor(v / s) == floor(floor(v) / s), and floor(v) fits an
-// int, so the rest is 24-bit integer work (full-rate VALU) instead of fp64.
-struct CellDiv {
-  float inv;
-  int s;
-  __device__ __forceinline__ explicit CellDiv(double scale) : inv(1.0f / (float)scale), s((int)scale) {}
-  __device__ __forceinline__ int operator()(double v) const {
-    const int vi = (int)v;  // truncation == floor for v >= 0
-    int q = (int)((float)vi * inv);
-    const int r = vi - q * s;
-    q += (r >= s) ? 1 : 0;
-    q -= (r < 0) ? 1 : 0;
-    return q;
-  }
-};
-
-// utils.py:593-609, 620-713; lane = ray.  (x0, y0, yaw0) is the pose BEFORE this step's control.
-//
-// The reference marches each ray sample by sample until it stops.  Here every lane runs the same fixed
-// number of samples (g.smax: after that many every ray is past `depth`), positions are the same iterated
-// sums, and the per-sample decisions are predicated on `alive` instead of steering control flow, so the
-// LDS lookups of consecutive samples overlap and no lane waits for the slowest ray.  Two exact shortcuts:
-//  * candidates: an agent can only be hit by ray i if its centre is within radius of the ray's LINE and
-//    not behind the drone; that conservative test runs once per (ray, candidate) and leaves a bit mask
-//    (almost always empty), only the set bits get the reference's exact per-sample circle test;
-//  * depth: sample k <= klo is nearer than `depth` for any slope, so `dist >= depth^2` is only evaluated
-//    for the last few samples.
-template <bool UNROLL>
-__device__ __forceinline__ void st_raycast(const d2d_cfg &c, const d2d_state &s, int e, int lane, const Geom &g,
-                                           const LdsView &L, const Consts &k_, double x0, double y0, double yaw0,
-                                           EnvRegs &r) {
-  const int N = c.N, W = c.W, H = c.H;
-  const unsigned char *gt = s.gt + (size_t)e * W * H;
-  unsigned char *dm = s.dmap + (size_t)e * W * H;
-  const double ss = c.scale - 1.0;  // x_step_size, utils.py:621
-  const CellDiv cell(c.scale);
-
-  // ---- stage the ground-truth window the rays can reach (LDS tile, OOB = wall) ----
-  const int ci0 = cell_fast(x0, c.scale, k_.inv_scale) - g.reach, cj0 = cell_fast(y0, c.scale, k_.inv_scale) - g.reach;
-  {
-    const FastDiv fd(g.ws);
-    for (int idx = lane; idx < g.ws * g.ws; idx += WAVE) {
-      int wi, wj;
-      fd.divmod(idx, wi, wj);
-      const int i = ci0 + wi, j = cj0 + wj;
-#ifdef D2D_ABL_NOSTAGE
-      L.gtw[idx] = (i > 0 && i < W - 1 && j > 0 && j < H - 1) ? 2 : 1;
-#else
-      L.gtw[idx] = (i >= 0 && i < W && j >= 0 && j < H) ? gt[(size_t)i * H + j] : (unsigned char)D2D_OCCUPIED;
-#endif
-    }
-  }
-
-  // ---- cull: only agents within reach of some ray sample can pass the circle test of :659 ----
-  // a sample is < depth + sqrt(2) * ss from the drone, so |agent - drone| <= radius + that bound
+// candidate compaction for the raycast (utils.py:658-662 tests every agent; only these can pass)
+__device__ __forceinline__ int ray_cull(const d2d_cfg &c, int lane, const LdsView &L, double x0, double y0) {
+  const int N = c.N;
+  const double ss = c.scale - 1.0;
   int ncand = 0;
   for (int k0 = 0; k0 < N; k0 += WAVE) {
     const int k = k0 + lane;
@@ -297,6 +435,7 @@ __device__ __forceinline__ void st_raycast(const d2d_cfg &c, const d2d_state &s,
       py = L.ay[k];
       r2 = L.ar2[k];
       rr = fabs(L.ar[k]);
+      // a sample is < depth + sqrt(2) * ss from the drone, so |agent - drone| <= radius + that bound
       const double lim = rr + c.depth + 1.5 * ss + 2.0;
       const double dx = px - x0, dy = py - y0;
       cand = (dx * dx + dy * dy <= lim * lim);
@@ -313,132 +452,130 @@ __device__ __forceinline__ void st_raycast(const d2d_cfg &c, const d2d_state &s,
     }
     ncand += __popcll(m);
   }
-#ifdef D2D_ABL_NOCAND
-  ncand = 0;
-#endif
-  wave_sync_lds();
-  D2D_STAMP(4);
+  return ncand;
+}
 
+// Per-ray setup (utils.py:594,626-650): direction steps and the conservative candidate mask.
+struct Ray {
+  double xs, ys;
+  unsigned int cmask;
+};
+
+__device__ __forceinline__ Ray ray_setup(const d2d_cfg &c, const LdsView &L, int i, int ncand, double x0, double y0,
+                                         double yaw0) {
+  const double ss = c.scale - 1.0;  // x_step_size, utils.py:621
   const double rad90 = 0x1.921fb54442d18p+0, rad270 = 0x1.2d97c7f3321d2p+2;  // radians(90), radians(270)
   const double pi_ = 0x1.921fb54442d18p+1;
   const double player_angle = 0x1.921fb54442d18p+2 - yaw0 * 0x1.1df46a2529d39p-6;  // pi*2 - radians(yaw)
-  const double depth2 = c.depth * c.depth;
-  const bool mask_path = ncand <= 32;
-
-  for (int i0 = 0; i0 < c.R; i0 += WAVE) {
-    const int i = i0 + lane;
-    const double ang = positive_angle(player_angle + (c.ray_off0 + c.ray_dth * (double)i));
-    const bool faced_right = (ang < rad90 || ang > rad270);
-    const bool faced_up = (ang > pi_);
+  const double ang = positive_angle(player_angle + (c.ray_off0 + c.ray_dth * (double)i));
+  const bool faced_right = (ang < rad90 || ang > rad270);
+  const bool faced_up = (ang > pi_);
 #ifdef D2D_ABL_NOTAN
-    double slope = ang * 0.3;
+  double slope = ang * 0.3;
 #else
-    double slope = d2d_tan(ang);
+  double slope = d2d_tan(ang);
 #endif
-    double xs, ys;
-    if (fabs(slope) > 1.0) {
-      slope = 1.0 / slope;
-      ys = faced_up ? -ss : ss;
-      xs = ys * slope;
-    } else {
-      xs = faced_right ? ss : -ss;
-      ys = xs * slope;
-    }
-
-    // per-ray candidate mask (conservative; the exact test stays per sample)
-    unsigned int cmask = 0;
-    if (mask_path) {
-      const double len2 = xs * xs + ys * ys, l1 = fabs(xs) + fabs(ys);
-      for (int q = 0; q < ncand; ++q) {
-        const double ex = L.cx[q] - x0, ey = L.cy[q] - y0, rq = L.crr[q] + 1e-6;
-        const double cr = ex * ys - ey * xs, dt = ex * xs + ey * ys;
-        const bool near_line = cr * cr <= rq * rq * len2 * (1.0 + 1e-9);
-        const bool ahead = dt + rq * l1 >= 0.0;
-        cmask |= (near_line && ahead) ? (1u << q) : 0u;
-      }
-    }
-
-    D2D_STAMP(5);
-    double x = x0, y = y0;
-    bool alive = (i < c.R) && (0.0 < x && x < c.W_px && 0.0 < y && y < c.H_px);
-    const int smax = g.smax, klo = g.klo;
-    auto sample = [&](int k) {
-      // exact circle tests (utils.py:658-662): every candidate that can matter, no early-out among agents
-      bool any = false;
-      if (mask_path) {
-        unsigned int m = alive ? cmask : 0u;
-        while (m) {
-          const int q = __ffs((int)m) - 1;
-          m &= m - 1;
-          const double dx = L.cx[q] - x, dy = L.cy[q] - y;
-          if (dx * dx + dy * dy <= L.cr2[q]) {
-            L.hit[L.cidx[q]] = 1;
-            any = true;
-          }
-        }
-      } else if (alive) {
-        for (int q = 0; q < ncand; ++q) {
-          const double dx = L.cx[q] - x, dy = L.cy[q] - y;
-          if (dx * dx + dy * dy <= L.cr2[q]) {
-            L.hit[L.cidx[q]] = 1;
-            any = true;
-          }
-        }
-      }
-      // the cell of this sample and its ground-truth value from the LDS tile.  Unconditional and clamped (a
-      // live sample always lies inside the tile: the previous sample was nearer than `depth`); it must not
-      // become a select between an LDS and a global pointer (flat load + vmcnt(0) wait per sample).
-      const double xc = alive ? x : x0, yc = alive ? y : y0;
-      const int ci = cell(xc), cj = cell(yc);
-      const int wi = min(max(ci - ci0, 0), g.ws - 1), wj = min(max(cj - cj0, 0), g.ws - 1);
-      const unsigned char wall = L.gtw[wi * g.ws + wj];
-      bool far = false;
-      if (k > klo) far = ((x - x0) * (x - x0) + (y - y0) * (y - y0) >= depth2);
-      const bool stop = (wall == D2D_OCCUPIED) || far;
-      if (alive && !any) {
-#ifndef D2D_ABL_NOSTORE
-        if (!stop) dm[(size_t)ci * H + cj] = D2D_UNOCCUPIED;
-        else if (wall == D2D_OCCUPIED) dm[(size_t)ci * H + cj] = D2D_OCCUPIED;
-#endif
-      }
-      alive = alive && !any && !stop;
-      x = x + xs;
-      y = y + ys;
-      alive = alive && (0.0 < x && x < c.W_px && 0.0 < y && y < c.H_px);
-    };
-#ifndef D2D_ABL_NOMARCH
-    if (UNROLL) {
-#pragma unroll
-      for (int k = 0; k < 10; ++k) sample(k);
-    } else {
-      for (int k = 0; k < smax; ++k) sample(k);
-    }
-#endif
+  Ray ry;
+  if (fabs(slope) > 1.0) {
+    slope = 1.0 / slope;
+    ry.ys = faced_up ? -ss : ss;
+    ry.xs = ry.ys * slope;
+  } else {
+    ry.xs = faced_right ? ss : -ss;
+    ry.ys = ry.xs * slope;
   }
-  wave_sync_lds();
-  D2D_STAMP(6);
-
-  // OR over rays happened in LDS; newly_tracked = #{hit and not active}, utils.py:603-607
-  int newly = 0;
-  for (int k0 = 0; k0 < N; k0 += WAVE) {
-    const int k = k0 + lane;
-    bool nw = false;
-    if (k < N) {
-      const unsigned char h = L.hit[k];
-      s.hit[(size_t)e * N + k] = h;
-      nw = h && !s.active[(size_t)e * N + k];
+  // An agent can only be hit by this ray if its centre is within radius of the ray's LINE and not behind
+  // the drone.  Conservative (margins cover the rounding of the iterated sample positions); the exact
+  // per-sample circle test of the reference is then applied to the set bits only.
+  ry.cmask = 0;
+  if (ncand <= 32) {
+    const double len2 = ry.xs * ry.xs + ry.ys * ry.ys, l1 = fabs(ry.xs) + fabs(ry.ys);
+    for (int q = 0; q < ncand; ++q) {
+      const double ex = L.cx[q] - x0, ey = L.cy[q] - y0, rq = L.crr[q] + 1e-6;
+      const double cr = ex * ry.ys - ey * ry.xs, dt = ex * ry.xs + ey * ry.ys;
+      const bool near_line = cr * cr <= rq * rq * len2 * (1.0 + 1e-9);
+      const bool ahead = dt + rq * l1 >= 0.0;
+      ry.cmask |= (near_line && ahead) ? (1u << q) : 0u;
     }
-    newly += __popcll(__ballot(nw));
   }
-  if (lane == 0) s.newly[e] = newly;
-  r.tracked += newly;
+  return ry;
 }
 
-// utils.py:527-540, lane = agent.  The reference clears every cell of dynamic_idx (== every DYNAMIC cell,
-// all of which lie in the blocks of dyn_prev) and then marks every agent's new block.  Written here as
-// ONE order-independent pass: the final value of a cell depends only on (static or not, covered by some
-// new block or not), so a lane may observe another lane's already-final value instead of the old one
-// without changing the outcome -- no clear/set ordering, no memory fence.
+// utils.py:620-713 for one ray (one lane).  Every lane runs the same fixed number of samples (g.smax: after
+// that many every ray is past `depth`); positions are the reference's iterated sums; the per-sample
+// decisions are predicated on `alive` instead of steering control flow, so consecutive samples' LDS
+// lookups overlap and no lane waits for the slowest ray.  `dist >= depth^2` is only evaluated for samples
+// k > klo (earlier ones are nearer than `depth` for any slope).
+template <bool UNROLL>
+__device__ __forceinline__ void ray_march(const d2d_cfg &c, const Geom &g, const LdsView &L, const Ray &ry, bool active,
+                                          int ncand, double x0, double y0, const Tile &wt, const Tile &ct, bool patch,
+                                          unsigned char *__restrict__ dm) {
+  const int H = c.H;
+  const CellDiv cell(c.scale);
+  const double depth2 = c.depth * c.depth;
+  const bool mask_path = ncand <= 32;
+  const unsigned char *gtw = (const unsigned char *)L.gtw;
+  unsigned char *dmt = (unsigned char *)L.dmt;
+  double x = x0, y = y0;
+  bool alive = active && (0.0 < x && x < c.W_px && 0.0 < y && y < c.H_px);
+  const int klo = g.klo;
+  auto sample = [&](int k) {
+    // exact circle tests (utils.py:658-662): every candidate that can matter, no early-out among agents
+    bool any = false;
+    if (mask_path) {
+      unsigned int m = alive ? ry.cmask : 0u;
+      while (m) {
+        const int q = __ffs((int)m) - 1;
+        m &= m - 1;
+        const double dx = L.cx[q] - x, dy = L.cy[q] - y;
+        if (dx * dx + dy * dy <= L.cr2[q]) {
+          L.hit[L.cidx[q]] = 1;
+          any = true;
+        }
+      }
+    } else if (alive) {
+      for (int q = 0; q < ncand; ++q) {
+        const double dx = L.cx[q] - x, dy = L.cy[q] - y;
+        if (dx * dx + dy * dy <= L.cr2[q]) {
+          L.hit[L.cidx[q]] = 1;
+          any = true;
+        }
+      }
+    }
+    // The cell of this sample and its ground-truth value from the LDS tile.  Unconditional and clamped (a
+    // live sample always lies inside the tile: the previous sample was nearer than `depth`); it must not
+    // become a select between an LDS and a global pointer (flat load + vmcnt(0) wait per sample).
+    const double xc = alive ? x : x0, yc = alive ? y : y0;
+    const int ci = cell(xc), cj = cell(yc);
+    const int wr = min(max(ci - wt.i0, 0), wt.rows - 1), wq = min(max(cj - wt.j0, 0), wt.cols - 1);
+    const unsigned char wall = gtw[wt.byte_index(wr, wq)];
+    bool far = false;
+    if (k > klo) far = ((x - x0) * (x - x0) + (y - y0) * (y - y0) >= depth2);
+    const bool stop = (wall == D2D_OCCUPIED) || far;
+    const bool write = alive && !any && (!stop || wall == D2D_OCCUPIED);
+    if (write) {
+      const unsigned char v = stop ? (unsigned char)D2D_OCCUPIED : (unsigned char)D2D_UNOCCUPIED;
+#ifndef D2D_ABL_NOSTORE
+      dm[ci * H + cj] = v;
+#endif
+      const int pr = ci - ct.i0, pq = cj - ct.j0;  // keep the observation tile in step with the map
+      if (patch && pr >= 0 && pr < ct.rows && pq >= 0 && pq < ct.cols) dmt[ct.byte_index(pr, pq)] = v;
+    }
+    alive = alive && !any && !stop;
+    x = x + ry.xs;
+    y = y + ry.ys;
+    alive = alive && (0.0 < x && x < c.W_px && 0.0 < y && y < c.H_px);
+  };
+#ifndef D2D_ABL_NOMARCH
+  if (UNROLL) {
+#pragma unroll
+    for (int k = 0; k < 10; ++k) sample(k);
+  } else {
+    for (int k = 0; k < g.smax; ++k) sample(k);
+  }
+#endif
+}
+
 // Is cell (i, j) inside the new block of ANY agent?  Straight loop, no early exit: the LDS reads are
 // broadcasts and pipeline.  Only used when the grid is too large for the LDS bitmap.
 __device__ __forceinline__ bool dyn_covered_loop(const LdsView &L, int N, int i, int j) {
@@ -447,93 +584,101 @@ __device__ __forceinline__ bool dyn_covered_loop(const LdsView &L, int N, int i,
   return cov;
 }
 
-__device__ __forceinline__ void st_dyngrid(const d2d_cfg &c, const d2d_state &s, int e, int lane, const Geom &g,
-                                           const LdsView &L) {
+// utils.py:527-540, lane = agent.  The reference clears every cell of dynamic_idx (== every DYNAMIC cell,
+// all of which lie in the blocks of dyn_prev) and then marks every agent's new block.  Written here as
+// ONE order-independent pass: the final value of a cell depends only on (static or not, covered by some
+// new block or not), so a lane may observe another lane's already-final value instead of the old one
+// without changing the outcome -- no clear/set ordering, no memory fence.  Coverage comes from an LDS
+// bitmap every agent ORs its new block into.
+struct DynCells {  // batch-2 loads of the common case (blocks of at most 3 x 3 cells)
+  unsigned char pv[9], nv[9];
+};
+
+__device__ __forceinline__ void dyn_bitmap(const d2d_cfg &c, int lane, const Geom &g, const LdsView &L) {
   const int N = c.N, W = c.W, H = c.H;
-  unsigned char *__restrict__ gt = s.gt + (size_t)e * W * H;
+  if (g.bmw == 0) return;
+  for (int w = lane; w < g.bmw; w += WAVE) L.bm[w] = 0u;
+  wave_sync_lds();
+  for (int k = lane; k < N; k += WAVE) {
+    const int cx = L.ncx[k], cy = L.ncy[k], u = L.nu[k];
+    const int i1 = min(cx + u + 1, W), j1 = min(cy + u + 1, H);
+    for (int i = max(cx - u, 0); i < i1; ++i)
+      for (int j = max(cy - u, 0); j < j1; ++j) {
+        const int bit = i * H + j;
+        atomicOr(&L.bm[bit >> 5], 1u << (bit & 31));
+      }
+  }
+}
+
+__device__ __forceinline__ void dyn_load(const d2d_cfg &c, const unsigned char *__restrict__ gt, int k, const LdsView &L,
+                                         DynCells &dc) {
+  const int W = c.W, H = c.H;
+  const int pcx = L.pcx[k], pcy = L.pcy[k], pu = L.pu[k], ncx = L.ncx[k], ncy = L.ncy[k], nu = L.nu[k];
+#pragma unroll
+  for (int q = 0; q < 9; ++q) {
+    const int di = q / 3 - 1, dj = q % 3 - 1;
+    const int i = pcx + di, j = pcy + dj;
+    const bool ok = pu <= 1 && nu <= 1 && abs(di) <= pu && abs(dj) <= pu && i >= 0 && i < W && j >= 0 && j < H;
+    dc.pv[q] = ok ? gt[i * H + j] : (unsigned char)D2D_OCCUPIED;
+    const int i2 = ncx + di, j2 = ncy + dj;
+    const bool ok2 = pu <= 1 && nu <= 1 && abs(di) <= nu && abs(dj) <= nu && i2 >= 0 && i2 < W && j2 >= 0 && j2 < H;
+    dc.nv[q] = ok2 ? gt[i2 * H + j2] : (unsigned char)D2D_OCCUPIED;
+  }
+}
+
+template <bool FAST>
+__device__ __forceinline__ void dyn_apply(const d2d_cfg &c, const d2d_state &s, int e, int k, const Geom &g,
+                                          const LdsView &L, unsigned char *__restrict__ gt, const DynCells &dc) {
+  const int N = c.N, W = c.W, H = c.H;
   int *prev = s.dyn_prev + (size_t)e * N * 3;
   const bool use_bm = g.bmw > 0;
-  if (use_bm) {  // coverage bitmap: every agent ORs the cells of its new block
-    for (int w = lane; w < g.bmw; w += WAVE) L.bm[w] = 0u;
-    wave_sync_lds();
-    for (int k = lane; k < N; k += WAVE) {
-      const int cx = L.ncx[k], cy = L.ncy[k], u = L.nu[k];
-      const int i1 = min(cx + u + 1, W), j1 = min(cy + u + 1, H);
-      for (int i = max(cx - u, 0); i < i1; ++i)
-        for (int j = max(cy - u, 0); j < j1; ++j) {
-          const int bit = i * H + j;
-          atomicOr(&L.bm[bit >> 5], 1u << (bit & 31));
-        }
-    }
-    wave_sync_lds();
-  }
-  for (int k = lane; k < N; k += WAVE) {
-    const int pcx = prev[3 * k], pcy = prev[3 * k + 1], pu = prev[3 * k + 2];
-    const int ncx = L.ncx[k], ncy = L.ncy[k], nu = L.nu[k];
-    if (pu <= 1 && nu <= 1) {
-      // common case (radius < 2 cells): all 18 cell reads are issued back to back, then the few writes
-      unsigned char pv[9], nv[9];
-      bool pcov[9];
+  const int pcx = L.pcx[k], pcy = L.pcy[k], pu = L.pu[k], ncx = L.ncx[k], ncy = L.ncy[k], nu = L.nu[k];
+  auto covered = [&](int i, int j) {
+    const int bit = i * H + j;
+    return use_bm ? ((L.bm[bit >> 5] >> (bit & 31)) & 1u) != 0u : dyn_covered_loop(L, N, i, j);
+  };
+  if (FAST && pu <= 1 && nu <= 1) {
 #pragma unroll
-      for (int q = 0; q < 9; ++q) {
-        const int di = q / 3 - 1, dj = q % 3 - 1;
-        const int i = pcx + di, j = pcy + dj;
-        const bool ok = abs(di) <= pu && abs(dj) <= pu && i >= 0 && i < W && j >= 0 && j < H;
-        pv[q] = ok ? gt[(size_t)i * H + j] : (unsigned char)D2D_OCCUPIED;
-        const int bit = ok ? i * H + j : 0;
-        pcov[q] = use_bm ? ((L.bm[bit >> 5] >> (bit & 31)) & 1u) != 0u : false;
-        const int i2 = ncx + di, j2 = ncy + dj;
-        const bool ok2 = abs(di) <= nu && abs(dj) <= nu && i2 >= 0 && i2 < W && j2 >= 0 && j2 < H;
-        nv[q] = ok2 ? gt[(size_t)i2 * H + j2] : (unsigned char)D2D_OCCUPIED;
-      }
-#pragma unroll
-      for (int q = 0; q < 9; ++q) {
-        const int di = q / 3 - 1, dj = q % 3 - 1;
-        if (pv[q] == D2D_DYNAMIC) {
-          const bool cov = use_bm ? pcov[q] : dyn_covered_loop(L, N, pcx + di, pcy + dj);
-          if (!cov) gt[(size_t)(pcx + di) * H + (pcy + dj)] = D2D_UNOCCUPIED;
-        }
-        if (nv[q] != D2D_OCCUPIED && nv[q] != D2D_DYNAMIC) gt[(size_t)(ncx + di) * H + (ncy + dj)] = D2D_DYNAMIC;
-      }
-    } else {
-      const int i1 = min(pcx + pu + 1, W), j1 = min(pcy + pu + 1, H);
-      for (int i = max(pcx - pu, 0); i < i1; ++i)
-        for (int j = max(pcy - pu, 0); j < j1; ++j)
-          if (gt[(size_t)i * H + j] == D2D_DYNAMIC) {
-            const int bit = i * H + j;
-            const bool cov = use_bm ? ((L.bm[bit >> 5] >> (bit & 31)) & 1u) != 0u : dyn_covered_loop(L, N, i, j);
-            if (!cov) gt[(size_t)i * H + j] = D2D_UNOCCUPIED;
-          }
-      const int i3 = min(ncx + nu + 1, W), j3 = min(ncy + nu + 1, H);
-      for (int i = max(ncx - nu, 0); i < i3; ++i)
-        for (int j = max(ncy - nu, 0); j < j3; ++j) {
-          const unsigned char v = gt[(size_t)i * H + j];
-          if (v != D2D_OCCUPIED && v != D2D_DYNAMIC) gt[(size_t)i * H + j] = D2D_DYNAMIC;
-        }
+    for (int q = 0; q < 9; ++q) {
+      const int di = q / 3 - 1, dj = q % 3 - 1;
+      if (dc.pv[q] == D2D_DYNAMIC && !covered(pcx + di, pcy + dj)) gt[(pcx + di) * H + (pcy + dj)] = D2D_UNOCCUPIED;
+      if (dc.nv[q] != D2D_OCCUPIED && dc.nv[q] != D2D_DYNAMIC) gt[(ncx + di) * H + (ncy + dj)] = D2D_DYNAMIC;
     }
-    prev[3 * k] = ncx;
-    prev[3 * k + 1] = ncy;
-    prev[3 * k + 2] = nu;
+  } else {
+    const int i1 = min(pcx + pu + 1, W), j1 = min(pcy + pu + 1, H);
+    for (int i = max(pcx - pu, 0); i < i1; ++i)
+      for (int j = max(pcy - pu, 0); j < j1; ++j)
+        if (gt[i * H + j] == D2D_DYNAMIC && !covered(i, j)) gt[i * H + j] = D2D_UNOCCUPIED;
+    const int i3 = min(ncx + nu + 1, W), j3 = min(ncy + nu + 1, H);
+    for (int i = max(ncx - nu, 0); i < i3; ++i)
+      for (int j = max(ncy - nu, 0); j < j3; ++j) {
+        const unsigned char v = gt[i * H + j];
+        if (v != D2D_OCCUPIED && v != D2D_DYNAMIC) gt[i * H + j] = D2D_DYNAMIC;
+      }
   }
+  if (pcx != ncx) prev[3 * k] = ncx;
+  if (pcy != ncy) prev[3 * k + 1] = ncy;
+  if (pu != nu) prev[3 * k + 2] = nu;
 }
 
 // ---- Kalman trackers, utils.py:172-275; lane = tracker slot ----
 // F = [[1,0,.1,0],[0,1,0,.1],[0,0,1,0],[0,0,0,1]] and H = [I2 0] are constant, so the dense products
 // of the reference collapse: multiplying by an exact 0 or 1 and adding an exact 0 do not round, hence the
 // sparse expressions below give the same values as the oracle's dense loops (tests compare bit for bit).
-__device__ __forceinline__ void st_tracker(const d2d_cfg &c, const d2d_state &s, int e, int lane, const LdsView &L,
-                                           EnvRegs &r) {
+template <bool KF_LDS>
+__device__ __forceinline__ void st_tracker(const d2d_cfg &c, const d2d_state &s, int e, int lane, const Geom &g,
+                                           const LdsView &L, EnvRegs &r) {
   const int N = c.N;
   int arch_n = 0, arch_ts = 0;
   for (int k0 = 0; k0 < N; k0 += WAVE) {
     const int k = k0 + lane;
     if (k < N) {
       const bool has_z = L.hit[k] != 0;
-      unsigned char act = s.active[(size_t)e * N + k];
+      unsigned char act = L.act[k];
       if (!c.kf_enabled) {
-        if (has_z) s.active[(size_t)e * N + k] = 1;
+        if (has_z && !act) s.active[(size_t)e * N + k] = 1;
       } else if (act || has_z) {
-        double *gk = s.kf + ((size_t)e * N + k) * D2D_KF;
+        double *__restrict__ gk = s.kf + ((size_t)e * N + k) * D2D_KF;
         int len = 1;
         double zx = L.ax[k], zy = L.ay[k];
         if (s.noise) {
@@ -543,11 +688,17 @@ __device__ __forceinline__ void st_tracker(const d2d_cfg &c, const d2d_state &s,
         double m0, m1, m2, m3;
         double S[16];
         if (act) {
-          len = s.kf_len[(size_t)e * N + k];
-          const double u0 = gk[0], u1 = gk[1], u2 = gk[2], u3 = gk[3];
-          double T[16];
+          len = L.klen[k];
+          double u0, u1, u2, u3, T[16];
+          if (KF_LDS) {
+            u0 = L.kf[0 * g.ncap + k]; u1 = L.kf[1 * g.ncap + k]; u2 = L.kf[2 * g.ncap + k]; u3 = L.kf[3 * g.ncap + k];
 #pragma unroll
-          for (int i = 0; i < 16; ++i) T[i] = gk[4 + i];
+            for (int i = 0; i < 16; ++i) T[i] = L.kf[(4 + i) * g.ncap + k];
+          } else {
+            u0 = gk[0]; u1 = gk[1]; u2 = gk[2]; u3 = gk[3];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) T[i] = gk[4 + i];
+          }
           // predict(), utils.py:225-240
           const double qn = (c.sigma != 0.0) ? 0.1 : 0.001;
           m0 = u0 + 0.1 * u2;
@@ -634,6 +785,8 @@ __device__ __forceinline__ void st_tracker(const d2d_cfg &c, const d2d_state &s,
         for (int i = 0; i < 16; ++i) gk[4 + i] = S[i];
         s.kf_len[(size_t)e * N + k] = len;
         s.active[(size_t)e * N + k] = act;
+        L.act[k] = act;
+        L.klen[k] = len;
       }
     }
   }
@@ -643,61 +796,12 @@ __device__ __forceinline__ void st_tracker(const d2d_cfg &c, const d2d_state &s,
   }
 }
 
-// envs/drone_v2.py:197-214 with utils.py:733-743, 755-762 (lane-uniform scalar work)
-__device__ __forceinline__ void st_control(const d2d_cfg &c, const d2d_state &s, int e, double action, EnvRegs &r) {
-  bool ok = true, has_wp = false;
-  if (c.planner_mode == D2D_PLANNER_NOMOVE) {
-    r.tx = -1.0;  // traj_planner.py:72
-    r.ty = -1.0;
-  } else {
-    ok = s.plan_ok[e] != 0;
-    has_wp = s.wp_valid[e] != 0;
-  }
-  if (!ok) {
-    const double n = sqrt(r.vx * r.vx + r.vy * r.vy);
-    if (n <= c.max_acc * c.dt) {
-      r.vx = 0.0;
-      r.vy = 0.0;
-    } else {
-      r.vx = r.vx - r.vx / n * c.max_acc * c.dt;
-      r.vy = r.vy - r.vy / n * c.max_acc * c.dt;
-      r.x += r.vx * c.dt;
-      r.y += r.vy * c.dt;
-    }
-    r.sm = D2D_SM_PLANNING;
-    r.fail += 1;
-  } else {
-    r.sm = D2D_SM_EXECUTING;
-    r.fail = 0;
-  }
-  if (has_wp) {
-    const double *wp = s.wp + (size_t)e * 6;
-    r.ax = wp[4];
-    r.ay = wp[5];
-    r.vx = wp[2];
-    r.vy = wp[3];
-    r.x = rint(wp[0]);  // round(): half to even
-    r.y = rint(wp[1]);
-  }
-  r.yaw = py_mod360(r.yaw + action * c.yaw_rate * c.dt);
-}
-
-// utils.py:764-778 + envs/drone_v2.py:217-235
+// utils.py:764-778 + envs/drone_v2.py:217-235.  `probe_wall`: the lane's batch-2 static probe (lane < 5).
 __device__ __forceinline__ void st_collide(const d2d_cfg &c, const d2d_state &s, int e, int lane, const LdsView &L,
-                                           const Consts &k_, EnvRegs &r) {
-  const int N = c.N, H = c.H;
-  const unsigned char *gt = s.gt + (size_t)e * c.W * H;
+                                           bool probe_wall, EnvRegs &r) {
+  const int N = c.N;
   const double R = c.drone_radius;
-  // static: 5 probe points, lane q < 5 (static cells never change, so no ordering with the dyn update)
-  bool wallhit = false;
-  if (lane < 5) {
-    const double ox = (lane == 0) ? -R : (lane == 2 ? R : 0.0);
-    const double oy = (lane == 3) ? -R : (lane == 4 ? R : 0.0);
-    const double qx = r.x + ox, qy = r.y + oy;
-    if (qx >= c.W_px || qx < 0.0 || qy >= c.H_px || qy < 0.0) wallhit = true;
-    else wallhit = gt[(size_t)cell_fast(qx, c.scale, k_.inv_scale) * H + cell_fast(qy, c.scale, k_.inv_scale)] == D2D_OCCUPIED;
-  }
-  int col = __any(wallhit) ? 1 : 0;
+  int col = __any(probe_wall) ? 1 : 0;
   if (!col) {
     bool dyn = false;
     for (int k = lane; k < N; k += WAVE) {
@@ -717,11 +821,12 @@ __device__ __forceinline__ void st_collide(const d2d_cfg &c, const d2d_state &s,
   const int done = (col != 0) || dead || frz || (r.sm == D2D_SM_GOAL_REACHED && r.tnext >= r.ntgt);
   if (done && c.kf_enabled) {  // drone_v2.py:232-235
     int an = 0, ats = 0;
-    for (int k = lane; k < N; k += WAVE)
-      if (s.active[(size_t)e * N + k]) {
+    for (int k = lane; k < N; k += WAVE) {
+      if (L.act[k] != 0) {
         an += 1;
-        ats += s.kf_len[(size_t)e * N + k];
+        ats += L.klen[k];
       }
+    }
     r.bufn += wave_sum(an);
     r.bufts += wave_sum(ats);
   }
@@ -734,32 +839,19 @@ __device__ __forceinline__ void st_collide(const d2d_cfg &c, const d2d_state &s,
   }
 }
 
-// utils.py:780-784 + envs/drone_v2.py:251-255.  Lanes sweep the L x L crop (rows of the map are
-// contiguous in memory); the loads of a chunk are all issued before its stores so the crop costs a
-// couple of memory round trips instead of one per 64 bytes.
-__device__ __forceinline__ void st_obs(const d2d_cfg &c, const d2d_state &s, int e, int lane, const Consts &k_,
-                                       const EnvRegs &r) {
-  const int Lm = c.L, edge = (Lm - 1) / 2, W = c.W, H = c.H, n = Lm * Lm;
-  const unsigned char *__restrict__ dm = s.dmap + (size_t)e * W * H;
+// utils.py:780-784 + envs/drone_v2.py:251-255: the crop is the LDS tile (loaded before the rays ran and
+// patched by them), zero outside the map.
+__device__ __forceinline__ void st_obs(const d2d_cfg &c, const d2d_state &s, int e, int lane, const LdsView &L,
+                                       const Tile &ct, const EnvRegs &r) {
+  const int Lm = c.L, W = c.W, H = c.H, n = Lm * Lm;
   unsigned char *__restrict__ ob = s.obs_local + (size_t)e * n;
-  const int ix = cell_fast(r.x, c.scale, k_.inv_scale) - edge, iy = cell_fast(r.y, c.scale, k_.inv_scale) - edge;
+  const unsigned char *dmt = (const unsigned char *)L.dmt;
   const FastDiv fd(Lm);
-  constexpr int CH = 9;  // 9 x 64 = 576 cells per chunk: L = 33 takes two chunks
-  for (int base = 0; base < n; base += CH * WAVE) {
-    unsigned char v[CH];
-#pragma unroll
-    for (int t = 0; t < CH; ++t) {
-      const int idx = base + t * WAVE + lane;
-      int p, q;
-      fd.divmod(idx, p, q);
-      const int i = ix + p, j = iy + q;
-      v[t] = (idx < n && i >= 0 && i < W && j >= 0 && j < H) ? dm[(size_t)i * H + j] : (unsigned char)0;
-    }
-#pragma unroll
-    for (int t = 0; t < CH; ++t) {
-      const int idx = base + t * WAVE + lane;
-      if (idx < n) ob[idx] = v[t];
-    }
+  for (int idx = lane; idx < n; idx += WAVE) {
+    int p, q;
+    fd.divmod(idx, p, q);
+    const int i = ct.i0 + p, j = ct.j0 + q;
+    ob[idx] = (i >= 0 && i < W && j >= 0 && j < H) ? dmt[ct.byte_index(p, q)] : (unsigned char)0;
   }
   if (lane == 0) s.obs_yaw[e] = (float)r.yaw;
 }
@@ -784,78 +876,139 @@ __device__ __forceinline__ void store_regs(const d2d_state &s, int e, const EnvR
   cn[D2D_C_TRACKED] = r.tracked; cn[D2D_C_BUF_N] = r.bufn; cn[D2D_C_BUF_TS] = r.bufts;
 }
 
-// One env-step (or any subset of its stages) by one wave.  Stage results are identical to running the
-// stages in reference order; the ORDER OF EXECUTION differs where that is free: the control stage only
-// consumes inputs (plan, action) and the previous pose, so it runs first and its memory latency overlaps
-// with everything else, while the raycast keeps using the pose from before it (x0, y0, yaw0).
+// One env-step (or any subset of its stages) by one wave.  Stage RESULTS are those of running the stages
+// in reference order; the ORDER OF EXECUTION differs where that is free:
+//  * the control stage consumes only inputs (plan, action) and the previous pose, so it runs first and the
+//    raycast keeps using the pose from before it (x0, y0, yaw0);
+//  * all loads addressed by batch-1 data (window, crop, grid cells, probes) are issued together, and the
+//    per-ray tan / candidate work runs while they are in flight.
 __device__ __forceinline__ void run_env(const d2d_cfg &c, const d2d_state &s, int e, int lane, uint32_t stages,
                                         const Geom &g, const LdsView &L, double action, EnvRegs &r) {
-  Consts k_;
-  k_.inv_scale = 1.0 / c.scale;
+  const int N = c.N, W = c.W, H = c.H;
+  const double inv_scale = 1.0 / c.scale;
+  const bool do_ray = stages & D2D_ST_RAYCAST, do_dyn = stages & D2D_ST_DYNGRID, do_trk = stages & D2D_ST_TRACKER;
+  const bool do_col = stages & D2D_ST_COLLIDE, do_obs = stages & D2D_ST_OBS, do_ctl = stages & D2D_ST_CONTROL;
+  unsigned char *__restrict__ gt = s.gt + (size_t)e * W * H;
+  unsigned char *__restrict__ dm = s.dmap + (size_t)e * W * H;
+
+  // ---------------- batch 1 ----------------
+  StepIn in;
+  load_inputs(c, s, e, action, do_ctl, in);
   D2D_STAMP(1);
   if (stages & D2D_ST_FSM) st_fsm(c, s, e, r);
   const double x0 = r.x, y0 = r.y, yaw0 = r.yaw;
-  if (stages & D2D_ST_CONTROL) st_control(c, s, e, action, r);
+  if (do_ctl) st_control(c, in, r);
   D2D_STAMP(2);
   const uint32_t needs_agents = D2D_ST_AGENTS | D2D_ST_RAYCAST | D2D_ST_DYNGRID | D2D_ST_TRACKER | D2D_ST_COLLIDE;
   if (stages & needs_agents) {
-    st_agents(c, s, e, lane, L, k_, (stages & D2D_ST_AGENTS) != 0);
+    st_agents(c, s, e, lane, g, L, inv_scale, (stages & D2D_ST_AGENTS) != 0, do_trk || do_col);
+    if (do_trk && !do_ray)  // hit mask of an earlier launch: stage it where the raycast leaves it
+      for (int k = lane; k < N; k += WAVE) L.hit[k] = s.hit[(size_t)e * N + k];
     wave_sync_lds();
   }
   D2D_STAMP(3);
-  if (stages & D2D_ST_RAYCAST) {
-    if (g.smax == 10 && g.klo == 6) st_raycast<true>(c, s, e, lane, g, L, k_, x0, y0, yaw0, r);  // depth 80, scale 10
-    else st_raycast<false>(c, s, e, lane, g, L, k_, x0, y0, yaw0, r);
+
+  // ---------------- batch 2 (addresses from batch-1 data) ----------------
+  const int ocx = cell_fast(x0, c.scale, inv_scale), ocy = cell_fast(y0, c.scale, inv_scale);
+  const int edge = (c.L - 1) / 2;
+  const Tile wt = make_tile(gt, H, ocx - g.reach, ocy - g.reach, g.ws, g.ws, g.wdw);
+  const Tile ct = make_tile(dm, H, cell_fast(r.x, c.scale, inv_scale) - edge, cell_fast(r.y, c.scale, inv_scale) - edge,
+                            c.L, c.L, g.ldw);
+  if (do_ray) tile_load(wt, L.gtw, W, lane, s.gt, s.gt + (size_t)c.B * W * H);
+  if (do_obs) tile_load(ct, L.dmt, W, lane, s.dmap, s.dmap + (size_t)c.B * W * H);
+  bool probe_wall = false;
+  if (do_col && lane < 5) {  // utils.py:766-771: static cells never change, so the probes can be read now
+    const double R = c.drone_radius;
+    const double ox = (lane == 0) ? -R : (lane == 2 ? R : 0.0);
+    const double oy = (lane == 3) ? -R : (lane == 4 ? R : 0.0);
+    const double qx = r.x + ox, qy = r.y + oy;
+    if (qx >= c.W_px || qx < 0.0 || qy >= c.H_px || qy < 0.0) probe_wall = true;
+    else probe_wall = gt[cell_fast(qx, c.scale, inv_scale) * H + cell_fast(qy, c.scale, inv_scale)] == D2D_OCCUPIED;
+  }
+  DynCells dc;
+  const bool dyn_fast = do_dyn && N <= WAVE;
+  if (dyn_fast && lane < N) dyn_load(c, gt, lane, L, dc);
+  if (do_dyn) dyn_bitmap(c, lane, g, L);
+
+  // ---------------- raycast: setup while batch 2 is in flight ----------------
+  int ncand = 0;
+  if (do_ray) {
+    ncand = ray_cull(c, lane, L, x0, y0);
+#ifdef D2D_ABL_NOCAND
+    ncand = 0;
+#endif
+  }
+  wave_sync_lds();
+  D2D_STAMP(4);
+  int newly = 0;
+  if (do_ray) {
+#ifdef D2D_NO_UNROLL
+    const bool unroll = false;
+#else
+    const bool unroll = (g.smax == 10 && g.klo == 6);  // depth 80, scale 10
+#endif
+    for (int i0 = 0; i0 < c.R; i0 += WAVE) {
+      const int i = i0 + lane;
+      const Ray ry = ray_setup(c, L, i, ncand, x0, y0, yaw0);
+      if (i0 == 0) {  // tiles have to be in LDS before the first sample reads / patches them
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        D2D_STAMP(5);
+      }
+      if (unroll) ray_march<true>(c, g, L, ry, i < c.R, ncand, x0, y0, wt, ct, do_obs, dm);
+      else ray_march<false>(c, g, L, ry, i < c.R, ncand, x0, y0, wt, ct, do_obs, dm);
+    }
+    wave_sync_lds();
+    D2D_STAMP(6);
+    // OR over rays happened in LDS; newly_tracked = #{hit and not active}, utils.py:603-607
+    for (int k0 = 0; k0 < N; k0 += WAVE) {
+      const int k = k0 + lane;
+      bool nw = false;
+      if (k < N) {
+        const unsigned char h = L.hit[k];
+        s.hit[(size_t)e * N + k] = h;
+        nw = h && !L.act[k];
+      }
+      newly += __popcll(__ballot(nw));
+    }
+    if (lane == 0) s.newly[e] = newly;
+    r.tracked += newly;
+  } else if (do_obs) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
   }
   D2D_STAMP(7);
-  if (stages & D2D_ST_DYNGRID) st_dyngrid(c, s, e, lane, g, L);
-  D2D_STAMP(8);
-  if (stages & D2D_ST_TRACKER) {
-    if (!(stages & D2D_ST_RAYCAST)) {  // hit mask of an earlier launch: stage it where the raycast leaves it
-      for (int k = lane; k < c.N; k += WAVE) L.hit[k] = s.hit[(size_t)e * c.N + k];
-      wave_sync_lds();
+  if (do_dyn) {
+    if (dyn_fast) {
+      if (lane < N) dyn_apply<true>(c, s, e, lane, g, L, gt, dc);
+    } else {
+      for (int k = lane; k < N; k += WAVE) dyn_apply<false>(c, s, e, k, g, L, gt, dc);
     }
-    st_tracker(c, s, e, lane, L, r);
+  }
+  D2D_STAMP(8);
+  if (do_trk) {  // two instantiations: a run-time choice between an LDS and a global pointer would become flat loads
+    if (g.kf_lds) st_tracker<true>(c, s, e, lane, g, L, r);
+    else st_tracker<false>(c, s, e, lane, g, L, r);
   }
   D2D_STAMP(9);
-  if (stages & D2D_ST_COLLIDE) st_collide(c, s, e, lane, L, k_, r);
+  if (do_col) st_collide(c, s, e, lane, L, probe_wall, r);
   D2D_STAMP(10);
-  if (stages & D2D_ST_OBS) {
-    if (stages & D2D_ST_RAYCAST) wave_sync_global();  // the crop re-reads cells the rays just wrote
-    D2D_STAMP(11);
-    st_obs(c, s, e, lane, k_, r);
-  }
+  D2D_STAMP(11);
+  if (do_obs) st_obs(c, s, e, lane, L, ct, r);
   D2D_STAMP(12);
-}
-
-__device__ __forceinline__ LdsView carve(char *base, const Geom &g) {
-  LdsView L;
-  L.ax = (double *)base;
-  L.ay = L.ax + g.ncap;
-  L.ar = L.ay + g.ncap;
-  L.ar2 = L.ar + g.ncap;
-  L.cx = L.ar2 + g.ncap;
-  L.cy = L.cx + g.ncap;
-  L.cr2 = L.cy + g.ncap;
-  L.crr = L.cr2 + g.ncap;
-  L.cidx = (int *)(L.crr + g.ncap);
-  L.ncx = L.cidx + g.ncap;
-  L.ncy = L.ncx + g.ncap;
-  L.nu = L.ncy + g.ncap;
-  L.bm = (unsigned int *)(L.nu + g.ncap);
-  L.hit = (unsigned char *)(L.bm + g.bmw);
-  L.gtw = L.hit + g.ncap;
-  return L;
 }
 
 extern __shared__ __attribute__((aligned(16))) char d2d_lds[];
 
 __global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK, D2D_MIN_WAVES) void k_stages(d2d_cfg c, d2d_state s, uint32_t stages) {
-  const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
-  const int e = blockIdx.x * WAVES_PER_BLOCK + wv;
+  // wave-uniform by construction; readfirstlane tells the compiler, so every per-env base pointer and LDS
+  // base lives in SGPRs and loads take the scalar-base + 32-bit-offset form
+  const int lane = threadIdx.x & (WAVE - 1), wpb = blockDim.x / WAVE;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);
+  const int e = blockIdx.x * wpb + wv;
   if (e >= c.B) return;
-  const Geom g = make_geom(c);
-  const LdsView L = carve(d2d_lds + (size_t)wv * g.wave_bytes, g);
+  const Geom g = make_geom(c, wpb);
+  const LdsView L = carve(d2d_lds + (size_t)wv * g.wave_bytes, g, c.L);
   EnvRegs r;
 #ifdef D2D_STAMPS
   if (d2d_stamp_buf && lane == 0) d2d_stamp_buf[(size_t)e * 16 + 0] = __builtin_amdgcn_s_memtime();
@@ -870,11 +1023,14 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK, D2D_MIN_WAVES) void k_stages
 __global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK) void k_rollout(d2d_cfg c, d2d_state s, int nsteps,
                                                                    const double *actions, const double *pin,
                                                                    unsigned char *coll_out) {
-  const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
-  const int e = blockIdx.x * WAVES_PER_BLOCK + wv;
+  // wave-uniform by construction; readfirstlane tells the compiler, so every per-env base pointer and LDS
+  // base lives in SGPRs and loads take the scalar-base + 32-bit-offset form
+  const int lane = threadIdx.x & (WAVE - 1), wpb = blockDim.x / WAVE;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);
+  const int e = blockIdx.x * wpb + wv;
   if (e >= c.B) return;
-  const Geom g = make_geom(c);
-  const LdsView L = carve(d2d_lds + (size_t)wv * g.wave_bytes, g);
+  const Geom g = make_geom(c, wpb);
+  const LdsView L = carve(d2d_lds + (size_t)wv * g.wave_bytes, g, c.L);
   EnvRegs r;
   load_regs(s, e, r);
   for (int t = 0; t < nsteps; ++t) {
@@ -947,6 +1103,13 @@ int fail(int code, const char *msg) {
   return code;
 }
 
+// envs per workgroup: as many waves as fit the 64 KB LDS budget (4, 2 or 1); 0 = does not fit at all
+int pick_wpb(const d2d_cfg &c) {
+  for (int wpb = WAVES_PER_BLOCK; wpb >= 1; wpb >>= 1)
+    if ((size_t)make_geom(c, wpb).wave_bytes * wpb <= 64 * 1024) return wpb;
+  return 0;
+}
+
 int check(const d2d_cfg *c, const d2d_state *s) {
   if (!c || !s) return fail(-1, "null cfg/state");
   if (c->abi_version != D2D_ABI_VERSION) return fail(-2, "ABI version mismatch");
@@ -960,8 +1123,7 @@ int check(const d2d_cfg *c, const d2d_state *s) {
   if (!s->agents || !s->agent_unit || !s->dyn_prev || !s->gt || !s->dmap || !s->drone || !s->target || !s->targets ||
       !s->counters || !s->active || !s->hit || !s->newly || !s->flags || !s->obs_local || !s->obs_yaw)
     return fail(-1, "null state pointer");
-  const Geom g = make_geom(*c);
-  if ((size_t)g.wave_bytes * WAVES_PER_BLOCK > 64 * 1024) return fail(-4, "N / view depth too large for the LDS tile");
+  if (pick_wpb(*c) == 0) return fail(-4, "N / view depth too large for the per-env LDS working set");
   return 0;
 }
 
@@ -972,11 +1134,12 @@ int launch_stages(const d2d_cfg *c, const d2d_state *s, uint32_t stages, void *s
   if ((stages & D2D_ST_CONTROL) && c->planner_mode == D2D_PLANNER_EXTERNAL && (!s->plan_ok || !s->wp_valid || !s->wp))
     return fail(-1, "external planner mode needs plan_ok / wp_valid / wp");
   if (c->B == 0) return 0;
-  const Geom g = make_geom(*c);
-  const dim3 grid((c->B + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK), block(WAVE * WAVES_PER_BLOCK);
+  const int wpb = pick_wpb(*c);
+  const Geom g = make_geom(*c, wpb);
+  const dim3 grid((c->B + wpb - 1) / wpb), block(WAVE * wpb);
   d2d_state st = *s;
   if (!st.action) st.action = (const double *)st.drone;  // never dereferenced meaningfully without CONTROL
-  hipLaunchKernelGGL(k_stages, grid, block, (size_t)g.wave_bytes * WAVES_PER_BLOCK, (hipStream_t)stream, *c, st, stages);
+  hipLaunchKernelGGL(k_stages, grid, block, (size_t)g.wave_bytes * wpb, (hipStream_t)stream, *c, st, stages);
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return fail(-3, hipGetErrorString(err));
   return 0;
@@ -1012,9 +1175,10 @@ int d2d_rollout(const d2d_cfg *c, const d2d_state *s, int32_t nsteps, const doub
   if (c->planner_mode == D2D_PLANNER_EXTERNAL && (!s->plan_ok || !s->wp_valid || !s->wp))
     return fail(-1, "external planner mode needs plan_ok / wp_valid / wp");
   if (c->B == 0 || nsteps == 0) return 0;
-  const Geom g = make_geom(*c);
-  const dim3 grid((c->B + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK), block(WAVE * WAVES_PER_BLOCK);
-  hipLaunchKernelGGL(k_rollout, grid, block, (size_t)g.wave_bytes * WAVES_PER_BLOCK, (hipStream_t)stream, *c, *s,
+  const int wpb = pick_wpb(*c);
+  const Geom g = make_geom(*c, wpb);
+  const dim3 grid((c->B + wpb - 1) / wpb), block(WAVE * wpb);
+  hipLaunchKernelGGL(k_rollout, grid, block, (size_t)g.wave_bytes * wpb, (hipStream_t)stream, *c, *s,
                      (int)nsteps, actions, pin, coll_out);
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return fail(-3, hipGetErrorString(err));
