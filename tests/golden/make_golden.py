@@ -162,7 +162,83 @@ def save(name, d):
     print(f'{name}: {os.path.getsize(path)/1024:.1f} KiB, steps={len(d.get("t_action", []))}')
 
 
+def survivability_cell_sweep(index, position_step=60, T=6.0):
+    """The reference's env_metrics (script/difficulty_calculator/glob_survivability_calculator.py:12-42),
+    driven verbatim (reset per start cell, pin the drone, step(0), record collision_flag == 2) for a
+    shortened horizon T."""
+    params = make_params(agent_number=index['agent_number'], agent_radius=index['agent_size'],
+                         agent_max_speed=index['agent_speed'], motion_profile='CVM', map_id=index['map_id'],
+                         gaze_method='NoControl', planner='NoMove', static_map='maps/empty_map.npy')
+    x_range = range(params.map_scale + params.drone_radius, params.map_size[0] - params.map_scale - params.drone_radius, position_step)
+    y_range = range(params.map_scale + params.drone_radius, params.map_size[1] - params.map_scale - params.drone_radius, position_step)
+    nt = len(np.arange(0, T, 0.1))
+    out = np.zeros((len(x_range), len(y_range), nt))
+    env = Drone2DEnv2(params)
+    for x in x_range:
+        for y in y_range:
+            env.reset()
+            for t in np.arange(0, T, 0.1):
+                env.drone.x = x
+                env.drone.y = y
+                _, _, done, info = env.step(0)
+                if info['collision_flag'] == 2:
+                    out[int((x - params.map_scale - params.drone_radius) / position_step),
+                        int((y - params.map_scale - params.drone_radius) / position_step), int(t / 0.1)] = 1
+    return out
+
+
+def gen_sweep():
+    d = {}
+    cfgs = [dict(agent_number=10, agent_size=10, agent_speed=40, map_id=0),
+            dict(agent_number=10, agent_size=15, agent_speed=60, map_id=3),
+            dict(agent_number=20, agent_size=5, agent_speed=20, map_id=1)]
+    for i, c in enumerate(cfgs):
+        d[f's{i}_cfg'] = np.array(json.dumps(c))
+        d[f's{i}_collision_state'] = survivability_cell_sweep(c, T=6.0).astype(np.uint8)
+    d['n'] = np.array(len(cfgs))
+    save('survivability_sweep', d)
+
+
+def experiment_row(params, policy_name):
+    """One episode driven like Experiment.run (experiment.py:65-103) and the values of its CSV row."""
+    from utils import state_machine
+    env = Drone2DEnv2(params)
+    pol = getattr(yaw_planner, policy_name)
+    pol.__init__(pol, params)
+    done = False
+    while not done:
+        a = pol.plan(pol, env.info)
+        _, _, done, info = env.step(a)
+    tracking_time = np.array([len(tr.ts) * 0.1 for tr in info['tracker_buffer']]).sum()
+    gm = info['drone'].map.grid_map
+    n = len(info['tracker_buffer'])
+    return [info['flight_time'], float(gm.shape[0] * gm.shape[1] - np.sum(np.where(gm == 0, 1, 0))), n,
+            float(tracking_time / n) if n else float('nan'),
+            1 if info['state_machine'] == state_machine['GOAL_REACHED'] else 0,
+            1 if info['collision_flag'] == 1 else 0, 1 if info['collision_flag'] == 2 else 0,
+            info['freezing_flag'], info['dead_lock_flag'], info['state_machine']]
+
+
+def gen_rows():
+    d = {}
+    cases = [('Oxford', dict(gaze_method='Oxford', planner='Primitive', agent_number=10, agent_max_speed=20,
+                             agent_radius=15, drone_max_speed=40, map_id=1)),
+             ('LookAhead', dict(gaze_method='LookAhead', planner='Primitive', agent_number=30, agent_max_speed=40,
+                                agent_radius=10, drone_max_speed=40, map_id=0)),
+             ('Rotating', dict(gaze_method='Rotating', planner='Primitive', agent_number=20, agent_max_speed=40,
+                               agent_radius=10, drone_max_speed=40, map_id=2))]
+    for i, (pol, kw) in enumerate(cases):
+        d[f'r{i}_cfg'] = np.array(json.dumps(kw))
+        d[f'r{i}_row'] = np.array(experiment_row(make_params(**kw), pol), dtype=np.float64)
+    d['n'] = np.array(len(cases))
+    save('experiment_rows', d)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == 'sweep':
+        return gen_sweep()
+    if len(sys.argv) > 1 and sys.argv[1] == 'rows':
+        return gen_rows()
     rng = np.random.RandomState(12345)
 
     # --- A. NoMove closed loop, BASELINE config-1/2 parameters, constant action (SURVEY section 4 KAT)
@@ -250,6 +326,8 @@ def main():
         maps[m + '_shape'] = np.array(a.shape)
         maps[m + '_xyl'] = np.stack([xs, ys, a[xs, ys]], axis=1).astype(np.int32).reshape(-1, 3)
     save('static_maps', maps)
+    gen_sweep()
+    gen_rows()
 
 
 if __name__ == '__main__':
