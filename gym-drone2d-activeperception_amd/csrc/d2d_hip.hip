@@ -33,7 +33,7 @@
 #define WAVE 64
 #define WAVES_PER_BLOCK 4
 #ifndef D2D_MIN_WAVES
-#define D2D_MIN_WAVES 3  // waves per SIMD the register allocator must leave room for
+#define D2D_MIN_WAVES 4  // waves per SIMD the register allocator must leave room for (4096 envs = 4 waves per SIMD)
 #endif
 
 #ifdef D2D_STAMPS
@@ -112,14 +112,14 @@ struct FastDiv {
 struct LdsView {
   double *ax, *ay, *ar, *ar2;    // all agents of the env after this step's move   [ncap]
   double *cx, *cy, *cr2, *crr;   // compacted ray candidates (centre, r^2, r)      [ncap]
-  double *kf;                    // tracker state staged in batch 1, plane-major   [20][ncap] (if g.kf_lds)
+  double *kf;                    // tracker state staged in batch 1 by DMA         [ncap][20] (if g.kf_lds)
   int *cidx;                     // candidate -> agent index                        [ncap]
   int *ncx, *ncy, *nu;           // new dynamic block of every agent (cell, half)   [ncap]
   int *pcx, *pcy, *pu;           // block written last time (dyn_prev)              [ncap]
   int *klen;                     // len(tracker.ts)                                 [ncap]
   unsigned int *bm;              // bitmap of cells covered by some agent's new block [bmw]
-  unsigned int *gtw;             // ground-truth window tile, dwords                [ws][wdw]
-  unsigned int *dmt;             // drone-map crop tile, dwords                     [L][ldw]
+  unsigned int *gtw;             // ground-truth window tile, bytes                 [ws][ws]
+  unsigned int *dmt;             // drone-map crop tile, bytes                      [L][L]
   unsigned char *hit, *act;      // per-agent hit flag (OR over rays), tracker.active [ncap]
 };
 
@@ -127,8 +127,8 @@ struct Geom {
   int ncap;   // N rounded up to a multiple of 4
   int reach;  // cells a ray can travel from the drone cell
   int ws;     // window edge = 2 * reach + 1
-  int wdw;    // dwords per window row (any byte alignment of the row start)
-  int ldw;    // dwords per crop row
+  int wdw;    // dwords of the window tile
+  int ldw;    // dwords of the crop tile
   int smax;   // samples after which every ray has stopped: sample k is >= k * ss from the drone
   int klo;    // samples 0..klo are < depth from the drone whatever the slope (k * ss * sqrt(2) < depth)
   int bmw;    // dwords of the per-env cell bitmap kept in LDS (0: grid too large, loop over agents instead)
@@ -137,14 +137,15 @@ struct Geom {
 };
 
 // `wpb`: waves (envs) per workgroup; the LDS budget of a workgroup is 64 KB
-__host__ __device__ inline Geom make_geom(const d2d_cfg &c, int wpb) {
+__host__ __device__ inline Geom make_geom(const d2d_cfg &c, int wpb, int ncap_fixed = 0) {
   Geom g;
   g.ncap = (c.N + 3) & ~3;
   if (g.ncap < 4) g.ncap = 4;
+  if (ncap_fixed) g.ncap = ncap_fixed;
   g.reach = (int)((c.depth + 1.5 * (c.scale - 1.0)) / c.scale) + 2;
   g.ws = 2 * g.reach + 1;
-  g.wdw = (g.ws + 6) / 4;
-  g.ldw = (c.L + 6) / 4;
+  g.wdw = (g.ws * g.ws + 3) / 4;   // dwords of the window tile
+  g.ldw = (c.L * c.L + 3) / 4;     // dwords of the crop tile
   const double ss = c.scale - 1.0;
   g.smax = (int)(c.depth / ss) + 2;
   const double kl = c.depth / (ss * 1.4142136);
@@ -152,7 +153,7 @@ __host__ __device__ inline Geom make_geom(const d2d_cfg &c, int wpb) {
   if (g.klo < -1) g.klo = -1;
   g.bmw = (c.W * c.H + 31) / 32;
   if (g.bmw > 2048) g.bmw = 0;  // 8 KB per wave at most (256 x 256 cells)
-  const int base = 64 * g.ncap + 32 * g.ncap + 4 * g.bmw + 4 * g.ws * g.wdw + 4 * c.L * g.ldw + 2 * g.ncap;
+  const int base = 64 * g.ncap + 32 * g.ncap + 4 * g.bmw + 4 * g.wdw + 4 * g.ldw + 2 * g.ncap;
   g.kf_lds = (c.kf_enabled && ((base + 160 * g.ncap + 15) & ~15) * wpb <= 64 * 1024) ? 1 : 0;
   g.wave_bytes = (base + (g.kf_lds ? 160 * g.ncap : 0) + 15) & ~15;
   return g;
@@ -179,8 +180,8 @@ __device__ __forceinline__ LdsView carve(char *base, const Geom &g, int Lm) {
   L.klen = L.pu + g.ncap;
   L.bm = (unsigned int *)(L.klen + g.ncap);
   L.gtw = L.bm + g.bmw;
-  L.dmt = L.gtw + g.ws * g.wdw;
-  L.hit = (unsigned char *)(L.dmt + Lm * g.ldw);
+  L.dmt = L.gtw + g.wdw;
+  L.hit = (unsigned char *)(L.dmt + g.ldw);
   L.act = L.hit + g.ncap;
   return L;
 }
@@ -218,50 +219,120 @@ struct CellDiv {
 };
 
 // ------------------------------------------------------------------------------------------------
-// LDS tiles of a uint8 grid, filled by LDS-DMA (global_load_lds_dword: no VGPRs, asynchronous)
+// LDS tiles of a uint8 grid
 // ------------------------------------------------------------------------------------------------
-// A tile covers `rows` x `cols` cells from cell (i0, j0).  Row r is kept as `ndw` dwords starting at the
-// 4-byte-aligned address at or below its first cell, so cell (r, q) sits at LDS byte r*ndw*4 + off(r) + q
-// with off(r) = (address of cell (i0 + r, j0)) & 3.  Cells outside the grid are never consulted (the
-// callers mask them), so rows / dwords outside it are simply not loaded.
+// A tile is the `rows` x `cols` block of cells from cell (i0, j0), one byte per cell, row-major, cells outside
+// the grid replaced by `fill`.  (An LDS-DMA variant with dword-aligned rows was measured: its per-dword
+// address arithmetic costs more wave instructions than these byte loads, and the kernel is bound by
+// instruction issue, not by VGPRs or bytes.)
 struct Tile {
-  long long a0;  // address of cell (i0, j0) (may lie outside the grid when i0 / j0 are negative)
-  int i0, j0, rows, cols, ndw, H;
-  __device__ __forceinline__ int off(int r) const { return (int)((a0 + (long long)r * H) & 3); }
-  __device__ __forceinline__ int byte_index(int r, int q) const { return r * ndw * 4 + off(r) + q; }
+  int i0, j0, rows, cols;
+  __device__ __forceinline__ int byte_index(int r, int q) const { return r * cols + q; }
 };
 
-__device__ __forceinline__ Tile make_tile(const unsigned char *grid, int H, int i0, int j0, int rows, int cols, int ndw) {
+__device__ __forceinline__ Tile make_tile(int i0, int j0, int rows, int cols) {
   Tile t;
-  t.a0 = (long long)(uintptr_t)grid + (long long)i0 * H + j0;
-  t.i0 = i0; t.j0 = j0; t.rows = rows; t.cols = cols; t.ndw = ndw; t.H = H;
+  t.i0 = i0; t.j0 = j0; t.rows = rows; t.cols = cols;
   return t;
 }
 
-// issue the DMA of a tile (the caller waits with vmcnt(0) before reading it)
-__device__ __forceinline__ void tile_load(const Tile &t, unsigned int *lds, int W, int lane, const unsigned char *lo,
-                                          const unsigned char *hi) {
-  const FastDiv fd(t.ndw);
-  const int n = t.rows * t.ndw;
-  for (int base = 0; base < n; base += WAVE) {
-    const int idx = base + lane;
-    int r, d;
-    fd.divmod(idx, r, d);
-    const int i = t.i0 + r;
-    const long long row0 = t.a0 + (long long)r * t.H;          // address of cell (i, j0)
-    const long long a = (row0 & ~3ll) + 4ll * d;               // this dword
-    const int jfirst = t.j0 + (int)(a - row0);                 // column of its first byte
-    const bool want = idx < n && i >= 0 && i < W && jfirst + 3 >= 0 && jfirst < t.H && jfirst < t.j0 + t.cols;
-    const unsigned char *ap = (const unsigned char *)(uintptr_t)a;
-    if (want && ap >= lo && ap + 4 <= hi) {
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)ap,
-                                       (__attribute__((address_space(3))) void *)(lds + base), 4, 0, 0);
-    } else if (want) {  // dword straddles the end of the whole tensor: byte by byte (first / last env only)
-      const __attribute__((address_space(1))) unsigned char *gp = (const __attribute__((address_space(1))) unsigned char *)ap;
-      unsigned int w = 0;
-      for (int b = 0; b < 4; ++b)
-        if (ap + b >= lo && ap + b < hi) w |= (unsigned int)gp[b] << (8 * b);
-      lds[idx] = w;
+// first CH x 64 cells of a tile: loads into registers / registers into LDS (split so that the loads of
+// several tiles can be in flight together)
+template <int CH>
+__device__ __forceinline__ void tile_fetch(const Tile &t, unsigned char (&v)[CH], const unsigned char *__restrict__ grid,
+                                           int W, int H, int lane, unsigned char fill) {
+  const FastDiv fd(t.cols);
+#pragma unroll
+  for (int u = 0; u < CH; ++u) {
+    const int idx = u * WAVE + lane;
+    int r, q;
+    fd.divmod(idx, r, q);
+    const int i = t.i0 + r, j = t.j0 + q;
+    // always a valid address (clamped), the fill is selected afterwards: a conditional load would become a
+    // branch around every load and serialize them
+    const unsigned char g = grid[min(max(i, 0), W - 1) * H + min(max(j, 0), H - 1)];
+    v[u] = (i >= 0 && i < W && j >= 0 && j < H) ? g : fill;
+  }
+}
+
+template <int CH>
+__device__ __forceinline__ void tile_put(const Tile &t, const unsigned char (&v)[CH], unsigned char *lds, int lane) {
+  const int n = t.rows * t.cols;
+#pragma unroll
+  for (int u = 0; u < CH; ++u) {
+    const int idx = u * WAVE + lane;
+    if (idx < n) lds[idx] = v[u];
+  }
+}
+
+// Two tiles at once, two rows per wave instruction: lanes 0-31 take row 2t, lanes 32-63 row 2t + 1, lane & 31 is
+// the column (tile A: cols <= 32; tile B: cols <= 33, its column 32 is swept by a last pass with lane = row).
+// MAXA / MAXB bound the row pairs held in registers (12 and 17: 23- and 33-row tiles).
+__device__ __forceinline__ void tile_rows2(const Tile &ta, unsigned char *la, const unsigned char *__restrict__ ga, int W,
+                                           int H, int lane, unsigned char fa, const Tile &tb, unsigned char *lb,
+                                           const unsigned char *__restrict__ gb, unsigned char fb) {
+  constexpr int MAXA = 12, MAXB = 17;
+  const int half = lane >> 5, col = lane & 31;
+  unsigned char va[MAXA], vb[MAXB], vc = 0;
+  {
+    const int j = ta.j0 + col, jc = min(max(j, 0), H - 1);
+    const bool jok = col < ta.cols && j >= 0 && j < H;
+#pragma unroll
+    for (int t = 0; t < MAXA; ++t) {
+      const int r = 2 * t + half, i = ta.i0 + r;
+      const unsigned char g = ga[min(max(i, 0), W - 1) * H + jc];
+      va[t] = (jok && i >= 0 && i < W) ? g : fa;
+    }
+  }
+  {
+    const int j = tb.j0 + col, jc = min(max(j, 0), H - 1);
+    const bool jok = j >= 0 && j < H;
+#pragma unroll
+    for (int t = 0; t < MAXB; ++t) {
+      const int r = 2 * t + half, i = tb.i0 + r;
+      const unsigned char g = gb[min(max(i, 0), W - 1) * H + jc];
+      vb[t] = (jok && i >= 0 && i < W) ? g : fb;
+    }
+    if (tb.cols > 32) {  // column 32 of every row, lane = row
+      const int i = tb.i0 + lane, j32 = tb.j0 + 32;
+      const unsigned char g = gb[min(max(i, 0), W - 1) * H + min(max(j32, 0), H - 1)];
+      vc = (i >= 0 && i < W && j32 >= 0 && j32 < H) ? g : fb;
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < MAXA; ++t) {
+    const int r = 2 * t + half;
+    if (r < ta.rows && col < ta.cols) la[r * ta.cols + col] = va[t];
+  }
+#pragma unroll
+  for (int t = 0; t < MAXB; ++t) {
+    const int r = 2 * t + half;
+    if (r < tb.rows) lb[r * tb.cols + col] = vb[t];
+  }
+  if (tb.cols > 32 && lane < tb.rows) lb[lane * tb.cols + 32] = vc;
+}
+
+// loads of up to CH x 64 cells are issued back to back, then written to LDS
+template <int CH>
+__device__ __forceinline__ void tile_load(const Tile &t, unsigned char *lds, const unsigned char *__restrict__ grid, int W,
+                                          int H, int lane, unsigned char fill) {
+  const FastDiv fd(t.cols);
+  const int n = t.rows * t.cols;
+  for (int base = 0; base < n; base += CH * WAVE) {
+    unsigned char v[CH];
+#pragma unroll
+    for (int u = 0; u < CH; ++u) {
+      const int idx = base + u * WAVE + lane;
+      int r, q;
+      fd.divmod(idx, r, q);
+      const int i = t.i0 + r, j = t.j0 + q;
+      const unsigned char g = grid[min(max(i, 0), W - 1) * H + min(max(j, 0), H - 1)];
+      v[u] = (i >= 0 && i < W && j >= 0 && j < H) ? g : fill;
+    }
+#pragma unroll
+    for (int u = 0; u < CH; ++u) {
+      const int idx = base + u * WAVE + lane;
+      if (idx < n) lds[idx] = v[u];
     }
   }
 }
@@ -360,21 +431,14 @@ __device__ __forceinline__ void st_agents(const d2d_cfg &c, const d2d_state &s, 
     const int p0 = prev[3 * k], p1 = prev[3 * k + 1], p2 = prev[3 * k + 2];
     const unsigned char act = s.active[(size_t)e * N + k];
     int klen = 1;
-    double kf[D2D_KF];
-    const bool stage_kf = want_trk && c.kf_enabled;
-    if (stage_kf) {
-      klen = s.kf_len[(size_t)e * N + k];
-      if (g.kf_lds) {
-        const double *__restrict__ gk = s.kf + ((size_t)e * N + k) * D2D_KF;
-#pragma unroll
-        for (int i = 0; i < D2D_KF; ++i) kf[i] = gk[i];
-      }
-    }
+    if (want_trk && c.kf_enabled) klen = s.kf_len[(size_t)e * N + k];
     if (move) {
       const double nx = px + velx * c.dt, ny = py + vely * c.dt;
       bool aliased = true;
       double pvx = velx, pvy = vely;
-      if (sqrt(velx * velx + vely * vely) <= 5.0) {
+      // norm(v) <= 5 (utils.py:476).  sqrt is correctly rounded and monotonic, and sqrt(s) rounds to <= 5 exactly
+      // for s <= nextafter(25) = 0x1.9000000000001p+4 (checked on the host), so the fp64 sqrt is not needed.
+      if (velx * velx + vely * vely <= 0x1.9000000000001p+4) {
         // numpy 2x2 @ 2x1 (OpenBLAS dgemv): fma(M[r][0], v0, M[r][1] * v1); see oracle/d2d_oracle.c
         const double rx = __builtin_fma(cs, velx, (-sn) * vely);
         const double ry = __builtin_fma(sn, velx, cs * vely);
@@ -406,10 +470,19 @@ __device__ __forceinline__ void st_agents(const d2d_cfg &c, const d2d_state &s, 
     L.pu[k] = p2;
     L.act[k] = act;
     L.klen[k] = klen;
-    if (stage_kf && g.kf_lds) {
-#pragma unroll
-      for (int i = 0; i < D2D_KF; ++i) L.kf[i * g.ncap + k] = kf[i];
-    }
+  }
+}
+
+// Tracker state of the env -> LDS by DMA (the env's [N][20] block is contiguous: 16-byte pieces, no VGPRs).
+// The caller's vmcnt(0) before the first tile read also covers this.
+__device__ __forceinline__ void kf_stage(const d2d_cfg &c, const d2d_state &s, int e, int lane, const LdsView &L) {
+  const int n16 = c.N * (D2D_KF * 8 / 16);
+  const char *src = (const char *)(s.kf + (size_t)e * c.N * D2D_KF);
+  for (int base = 0; base < n16; base += WAVE) {
+    const int idx = base + lane;
+    if (idx < n16)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + (size_t)idx * 16),
+                                       (__attribute__((address_space(3))) void *)((char *)L.kf + (size_t)base * 16), 16, 0, 0);
   }
 }
 
@@ -506,7 +579,6 @@ __device__ __forceinline__ Ray ray_setup(const d2d_cfg &c, const LdsView &L, int
 // decisions are predicated on `alive` instead of steering control flow, so consecutive samples' LDS
 // lookups overlap and no lane waits for the slowest ray.  `dist >= depth^2` is only evaluated for samples
 // k > klo (earlier ones are nearer than `depth` for any slope).
-template <bool UNROLL>
 __device__ __forceinline__ void ray_march(const d2d_cfg &c, const Geom &g, const LdsView &L, const Ray &ry, bool active,
                                           int ncand, double x0, double y0, const Tile &wt, const Tile &ct, bool patch,
                                           unsigned char *__restrict__ dm) {
@@ -519,11 +591,23 @@ __device__ __forceinline__ void ray_march(const d2d_cfg &c, const Geom &g, const
   double x = x0, y = y0;
   bool alive = active && (0.0 < x && x < c.W_px && 0.0 < y && y < c.H_px);
   const int klo = g.klo;
+  // The first candidate of this ray's mask (almost always the only one) is tested from registers on every
+  // sample, branch-free; further candidates (rare) go through the LDS loop.
+  const bool has1 = mask_path && ry.cmask != 0u;
+  const int q1 = has1 ? (__ffs((int)ry.cmask) - 1) : 0;
+  const double c1x = L.cx[q1], c1y = L.cy[q1], c1r2 = has1 ? L.cr2[q1] : -1.0;
+  const int c1i = L.cidx[q1];
+  const unsigned int rest = mask_path ? (ry.cmask & (ry.cmask - 1u)) : 0u;
   auto sample = [&](int k) {
     // exact circle tests (utils.py:658-662): every candidate that can matter, no early-out among agents
     bool any = false;
+    {
+      const double dx = c1x - x, dy = c1y - y;
+      any = alive && (dx * dx + dy * dy <= c1r2);
+      if (any) L.hit[c1i] = 1;
+    }
     if (mask_path) {
-      unsigned int m = alive ? ry.cmask : 0u;
+      unsigned int m = alive ? rest : 0u;
       while (m) {
         const int q = __ffs((int)m) - 1;
         m &= m - 1;
@@ -567,12 +651,7 @@ __device__ __forceinline__ void ray_march(const d2d_cfg &c, const Geom &g, const
     alive = alive && (0.0 < x && x < c.W_px && 0.0 < y && y < c.H_px);
   };
 #ifndef D2D_ABL_NOMARCH
-  if (UNROLL) {
-#pragma unroll
-    for (int k = 0; k < 10; ++k) sample(k);
-  } else {
-    for (int k = 0; k < g.smax; ++k) sample(k);
-  }
+  for (int k = 0; k < g.smax; ++k) sample(k);  // not unrolled: a 10x body overflows the instruction cache
 #endif
 }
 
@@ -590,8 +669,9 @@ __device__ __forceinline__ bool dyn_covered_loop(const LdsView &L, int N, int i,
 // new block or not), so a lane may observe another lane's already-final value instead of the old one
 // without changing the outcome -- no clear/set ordering, no memory fence.  Coverage comes from an LDS
 // bitmap every agent ORs its new block into.
-struct DynCells {  // batch-2 loads of the common case (blocks of at most 3 x 3 cells)
-  unsigned char pv[9], nv[9];
+struct DynCells {  // the common case (blocks of at most 3 x 3 cells), reduced to what the update needs
+  unsigned int pdyn;   // bit q: previous-block cell q holds DYNAMIC
+  unsigned int nfree;  // bit q: new-block cell q is neither static nor already DYNAMIC
 };
 
 __device__ __forceinline__ void dyn_bitmap(const d2d_cfg &c, int lane, const Geom &g, const LdsView &L) {
@@ -614,15 +694,38 @@ __device__ __forceinline__ void dyn_load(const d2d_cfg &c, const unsigned char *
                                          DynCells &dc) {
   const int W = c.W, H = c.H;
   const int pcx = L.pcx[k], pcy = L.pcy[k], pu = L.pu[k], ncx = L.ncx[k], ncy = L.ncy[k], nu = L.nu[k];
+  unsigned char pv[9], nv[9];
+  const bool small = pu <= 1 && nu <= 1;
+  const bool interior = pcx >= 1 && pcx <= W - 2 && pcy >= 1 && pcy <= H - 2 && ncx >= 1 && ncx <= W - 2 && ncy >= 1 &&
+                        ncy <= H - 2;
+  if (__all(interior || !small)) {
+    // every 3 x 3 block of the wave lies inside the grid (agents keep a radius away from the border): one
+    // address per block, the nine cells at constant offsets
+    const unsigned char *pp = gt + (interior ? pcx * H + pcy : H + 1), *np = gt + (interior ? ncx * H + ncy : H + 1);
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+      const int o = (q / 3 - 1) * H + (q % 3 - 1);
+      pv[q] = pp[o];
+      nv[q] = np[o];
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {  // clamped (always valid) addresses
+      const int di = q / 3 - 1, dj = q % 3 - 1;
+      pv[q] = gt[min(max(pcx + di, 0), W - 1) * H + min(max(pcy + dj, 0), H - 1)];
+      nv[q] = gt[min(max(ncx + di, 0), W - 1) * H + min(max(ncy + dj, 0), H - 1)];
+    }
+  }
+  dc.pdyn = 0;
+  dc.nfree = 0;
 #pragma unroll
   for (int q = 0; q < 9; ++q) {
     const int di = q / 3 - 1, dj = q % 3 - 1;
-    const int i = pcx + di, j = pcy + dj;
-    const bool ok = pu <= 1 && nu <= 1 && abs(di) <= pu && abs(dj) <= pu && i >= 0 && i < W && j >= 0 && j < H;
-    dc.pv[q] = ok ? gt[i * H + j] : (unsigned char)D2D_OCCUPIED;
-    const int i2 = ncx + di, j2 = ncy + dj;
-    const bool ok2 = pu <= 1 && nu <= 1 && abs(di) <= nu && abs(dj) <= nu && i2 >= 0 && i2 < W && j2 >= 0 && j2 < H;
-    dc.nv[q] = ok2 ? gt[i2 * H + j2] : (unsigned char)D2D_OCCUPIED;
+    const int i = pcx + di, j = pcy + dj, i2 = ncx + di, j2 = ncy + dj;
+    const bool ok = small && abs(di) <= pu && abs(dj) <= pu && i >= 0 && i < W && j >= 0 && j < H;
+    const bool ok2 = small && abs(di) <= nu && abs(dj) <= nu && i2 >= 0 && i2 < W && j2 >= 0 && j2 < H;
+    dc.pdyn |= (ok && pv[q] == D2D_DYNAMIC) ? (1u << q) : 0u;
+    dc.nfree |= (ok2 && nv[q] != D2D_OCCUPIED && nv[q] != D2D_DYNAMIC) ? (1u << q) : 0u;
   }
 }
 
@@ -638,11 +741,18 @@ __device__ __forceinline__ void dyn_apply(const d2d_cfg &c, const d2d_state &s, 
     return use_bm ? ((L.bm[bit >> 5] >> (bit & 31)) & 1u) != 0u : dyn_covered_loop(L, N, i, j);
   };
   if (FAST && pu <= 1 && nu <= 1) {
+    bool cov[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {  // coverage of the 9 previous cells: independent LDS reads, one wait
+      const int i = min(max(pcx + q / 3 - 1, 0), W - 1), j = min(max(pcy + q % 3 - 1, 0), H - 1);
+      const int bit = i * H + j;
+      cov[q] = use_bm ? ((L.bm[bit >> 5] >> (bit & 31)) & 1u) != 0u : dyn_covered_loop(L, N, i, j);
+    }
 #pragma unroll
     for (int q = 0; q < 9; ++q) {
       const int di = q / 3 - 1, dj = q % 3 - 1;
-      if (dc.pv[q] == D2D_DYNAMIC && !covered(pcx + di, pcy + dj)) gt[(pcx + di) * H + (pcy + dj)] = D2D_UNOCCUPIED;
-      if (dc.nv[q] != D2D_OCCUPIED && dc.nv[q] != D2D_DYNAMIC) gt[(ncx + di) * H + (ncy + dj)] = D2D_DYNAMIC;
+      if (((dc.pdyn >> q) & 1u) && !cov[q]) gt[(pcx + di) * H + (pcy + dj)] = D2D_UNOCCUPIED;
+      if ((dc.nfree >> q) & 1u) gt[(ncx + di) * H + (ncy + dj)] = D2D_DYNAMIC;
     }
   } else {
     const int i1 = min(pcx + pu + 1, W), j1 = min(pcy + pu + 1, H);
@@ -689,36 +799,30 @@ __device__ __forceinline__ void st_tracker(const d2d_cfg &c, const d2d_state &s,
         double S[16];
         if (act) {
           len = L.klen[k];
-          double u0, u1, u2, u3, T[16];
           if (KF_LDS) {
-            u0 = L.kf[0 * g.ncap + k]; u1 = L.kf[1 * g.ncap + k]; u2 = L.kf[2 * g.ncap + k]; u3 = L.kf[3 * g.ncap + k];
+            const double *lk = L.kf + k * D2D_KF;
+            m0 = lk[0]; m1 = lk[1]; m2 = lk[2]; m3 = lk[3];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) T[i] = L.kf[(4 + i) * g.ncap + k];
+            for (int i = 0; i < 16; ++i) S[i] = lk[4 + i];
           } else {
-            u0 = gk[0]; u1 = gk[1]; u2 = gk[2]; u3 = gk[3];
+            m0 = gk[0]; m1 = gk[1]; m2 = gk[2]; m3 = gk[3];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) T[i] = gk[4 + i];
+            for (int i = 0; i < 16; ++i) S[i] = gk[4 + i];
           }
-          // predict(), utils.py:225-240
+          // predict(), utils.py:225-240, in place (each line only reads entries not yet overwritten):
+          // mu <- F mu ; S <- F S ; S <- S F^T ; S += Q
           const double qn = (c.sigma != 0.0) ? 0.1 : 0.001;
-          m0 = u0 + 0.1 * u2;
-          m1 = u1 + 0.1 * u3;
-          m2 = u2;
-          m3 = u3;
-          double FS[16];
+          m0 = m0 + 0.1 * m2;
+          m1 = m1 + 0.1 * m3;
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            FS[j] = T[j] + 0.1 * T[8 + j];
-            FS[4 + j] = T[4 + j] + 0.1 * T[12 + j];
-            FS[8 + j] = T[8 + j];
-            FS[12 + j] = T[12 + j];
+            S[j] = S[j] + 0.1 * S[8 + j];
+            S[4 + j] = S[4 + j] + 0.1 * S[12 + j];
           }
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            S[4 * i + 0] = FS[4 * i + 0] + FS[4 * i + 2] * 0.1;
-            S[4 * i + 1] = FS[4 * i + 1] + FS[4 * i + 3] * 0.1;
-            S[4 * i + 2] = FS[4 * i + 2];
-            S[4 * i + 3] = FS[4 * i + 3];
+            S[4 * i + 0] = S[4 * i + 0] + S[4 * i + 2] * 0.1;
+            S[4 * i + 1] = S[4 * i + 1] + S[4 * i + 3] * 0.1;
           }
 #pragma unroll
           for (int i = 0; i < 4; ++i) S[5 * i] += qn;
@@ -739,7 +843,8 @@ __device__ __forceinline__ void st_tracker(const d2d_cfg &c, const d2d_state &s,
           if (has_z) {  // update, utils.py:249-260 (also runs on the freshly reset filter)
             const double a = c.sigma + S[0], b = S[1], cc = S[4], d = c.sigma + S[5];
             const double det = a * d - b * cc;
-            const double i00 = d / det, i01 = -b / det, i10 = -cc / det, i11 = a / det;
+            const double idet = 1.0 / det;  // inv(S) through one reciprocal (same in oracle/d2d_oracle.c)
+            const double i00 = d * idet, i01 = -b * idet, i10 = -cc * idet, i11 = a * idet;
             double K0[4], K1[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -747,21 +852,19 @@ __device__ __forceinline__ void st_tracker(const d2d_cfg &c, const d2d_state &s,
               K1[i] = S[4 * i] * i01 + S[4 * i + 1] * i11;
             }
             const double rx = zx - m0, ry = zy - m1;
-            double P[16];
             const double e00 = 1.0 - K0[0], e01 = 0.0 - K1[0], e10 = 0.0 - K0[1], e11 = 1.0 - K1[1];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              P[j] = e00 * S[j] + e01 * S[4 + j];
-              P[4 + j] = e10 * S[j] + e11 * S[4 + j];
-              P[8 + j] = ((0.0 - K0[2]) * S[j] + (0.0 - K1[2]) * S[4 + j]) + S[8 + j];
-              P[12 + j] = ((0.0 - K0[3]) * S[j] + (0.0 - K1[3]) * S[4 + j]) + S[12 + j];
+            for (int j = 0; j < 4; ++j) {  // S <- (I - K H) S, rows 2,3 first (they read rows 0,1), then 0,1
+              const double s0 = S[j], s1 = S[4 + j];
+              S[8 + j] = ((0.0 - K0[2]) * s0 + (0.0 - K1[2]) * s1) + S[8 + j];
+              S[12 + j] = ((0.0 - K0[3]) * s0 + (0.0 - K1[3]) * s1) + S[12 + j];
+              S[j] = e00 * s0 + e01 * s1;
+              S[4 + j] = e10 * s0 + e11 * s1;
             }
             m0 = m0 + (K0[0] * rx + K1[0] * ry);
             m1 = m1 + (K0[1] * rx + K1[1] * ry);
             m2 = m2 + (K0[2] * rx + K1[2] * ry);
             m3 = m3 + (K0[3] * rx + K1[3] * ry);
-#pragma unroll
-            for (int i = 0; i < 16; ++i) S[i] = P[i];
           }
         } else {  // first sighting, utils.py:263-273
           m0 = zx;
@@ -805,8 +908,13 @@ __device__ __forceinline__ void st_collide(const d2d_cfg &c, const d2d_state &s,
   if (!col) {
     bool dyn = false;
     for (int k = lane; k < N; k += WAVE) {
-      const double dx = L.ax[k] - r.x, dy = L.ay[k] - r.y;
-      dyn = dyn || (sqrt(dx * dx + dy * dy) < L.ar[k] + R);
+      // norm(d) < r + R (utils.py:774): decided by d.d against (r + R)^2 unless they agree to 1e-14, where the
+      // correctly rounded sqrt of the reference decides
+      const double dx = L.ax[k] - r.x, dy = L.ay[k] - r.y, t = L.ar[k] + R;
+      const double d2 = dx * dx + dy * dy, t2 = t * t;
+      bool hit = d2 < t2 && t > 0.0;
+      if (fabs(d2 - t2) <= 1e-14 * t2) hit = sqrt(d2) < t;
+      dyn = dyn || hit;
     }
     if (__any(dyn)) col = 2;
   }
@@ -839,20 +947,14 @@ __device__ __forceinline__ void st_collide(const d2d_cfg &c, const d2d_state &s,
   }
 }
 
-// utils.py:780-784 + envs/drone_v2.py:251-255: the crop is the LDS tile (loaded before the rays ran and
-// patched by them), zero outside the map.
+// utils.py:780-784 + envs/drone_v2.py:251-255: the crop is the LDS tile (loaded before the rays ran, zero
+// outside the map, patched by the rays), copied out as it is.
 __device__ __forceinline__ void st_obs(const d2d_cfg &c, const d2d_state &s, int e, int lane, const LdsView &L,
-                                       const Tile &ct, const EnvRegs &r) {
-  const int Lm = c.L, W = c.W, H = c.H, n = Lm * Lm;
+                                       const EnvRegs &r) {
+  const int n = c.L * c.L;
   unsigned char *__restrict__ ob = s.obs_local + (size_t)e * n;
   const unsigned char *dmt = (const unsigned char *)L.dmt;
-  const FastDiv fd(Lm);
-  for (int idx = lane; idx < n; idx += WAVE) {
-    int p, q;
-    fd.divmod(idx, p, q);
-    const int i = ct.i0 + p, j = ct.j0 + q;
-    ob[idx] = (i >= 0 && i < W && j >= 0 && j < H) ? dmt[ct.byte_index(p, q)] : (unsigned char)0;
-  }
+  for (int idx = lane; idx < n; idx += WAVE) ob[idx] = dmt[idx];
   if (lane == 0) s.obs_yaw[e] = (float)r.yaw;
 }
 
@@ -900,6 +1002,7 @@ __device__ __forceinline__ void run_env(const d2d_cfg &c, const d2d_state &s, in
   if (do_ctl) st_control(c, in, r);
   D2D_STAMP(2);
   const uint32_t needs_agents = D2D_ST_AGENTS | D2D_ST_RAYCAST | D2D_ST_DYNGRID | D2D_ST_TRACKER | D2D_ST_COLLIDE;
+  if (do_trk && c.kf_enabled && g.kf_lds) kf_stage(c, s, e, lane, L);
   if (stages & needs_agents) {
     st_agents(c, s, e, lane, g, L, inv_scale, (stages & D2D_ST_AGENTS) != 0, do_trk || do_col);
     if (do_trk && !do_ray)  // hit mask of an earlier launch: stage it where the raycast leaves it
@@ -911,24 +1014,32 @@ __device__ __forceinline__ void run_env(const d2d_cfg &c, const d2d_state &s, in
   // ---------------- batch 2 (addresses from batch-1 data) ----------------
   const int ocx = cell_fast(x0, c.scale, inv_scale), ocy = cell_fast(y0, c.scale, inv_scale);
   const int edge = (c.L - 1) / 2;
-  const Tile wt = make_tile(gt, H, ocx - g.reach, ocy - g.reach, g.ws, g.ws, g.wdw);
-  const Tile ct = make_tile(dm, H, cell_fast(r.x, c.scale, inv_scale) - edge, cell_fast(r.y, c.scale, inv_scale) - edge,
-                            c.L, c.L, g.ldw);
-  if (do_ray) tile_load(wt, L.gtw, W, lane, s.gt, s.gt + (size_t)c.B * W * H);
-  if (do_obs) tile_load(ct, L.dmt, W, lane, s.dmap, s.dmap + (size_t)c.B * W * H);
+  const Tile wt = make_tile(ocx - g.reach, ocy - g.reach, g.ws, g.ws);
+  const Tile ct = make_tile(cell_fast(r.x, c.scale, inv_scale) - edge, cell_fast(r.y, c.scale, inv_scale) - edge, c.L, c.L);
+  if (do_ray && do_obs && wt.cols <= 32 && wt.rows <= 24 && ct.cols <= 33 && ct.rows <= 34) {
+    // default geometry (23 x 23 window, 33 x 33 crop): lanes map to (row parity, column), so a cell costs an
+    // add and a compare instead of a division; all loads of both tiles are in flight before the first LDS write
+    tile_rows2(wt, (unsigned char *)L.gtw, gt, W, H, lane, (unsigned char)D2D_OCCUPIED,
+               ct, (unsigned char *)L.dmt, dm, (unsigned char)0);
+  } else {
+    if (do_ray) tile_load<9>(wt, (unsigned char *)L.gtw, gt, W, H, lane, (unsigned char)D2D_OCCUPIED);
+    if (do_obs) tile_load<9>(ct, (unsigned char *)L.dmt, dm, W, H, lane, (unsigned char)0);
+  }
   bool probe_wall = false;
   if (do_col && lane < 5) {  // utils.py:766-771: static cells never change, so the probes can be read now
     const double R = c.drone_radius;
     const double ox = (lane == 0) ? -R : (lane == 2 ? R : 0.0);
     const double oy = (lane == 3) ? -R : (lane == 4 ? R : 0.0);
     const double qx = r.x + ox, qy = r.y + oy;
-    if (qx >= c.W_px || qx < 0.0 || qy >= c.H_px || qy < 0.0) probe_wall = true;
-    else probe_wall = gt[cell_fast(qx, c.scale, inv_scale) * H + cell_fast(qy, c.scale, inv_scale)] == D2D_OCCUPIED;
+    const bool oob = (qx >= c.W_px || qx < 0.0 || qy >= c.H_px || qy < 0.0);
+    const int pi = min(max(cell_fast(qx, c.scale, inv_scale), 0), W - 1), pj = min(max(cell_fast(qy, c.scale, inv_scale), 0), H - 1);
+    probe_wall = oob || gt[pi * H + pj] == D2D_OCCUPIED;
   }
-  DynCells dc;
   const bool dyn_fast = do_dyn && N <= WAVE;
-  if (dyn_fast && lane < N) dyn_load(c, gt, lane, L, dc);
   if (do_dyn) dyn_bitmap(c, lane, g, L);
+  DynCells dc;
+  dc.pdyn = dc.nfree = 0;
+  if (dyn_fast && lane < N) dyn_load(c, gt, lane, L, dc);
 
   // ---------------- raycast: setup while batch 2 is in flight ----------------
   int ncand = 0;
@@ -942,21 +1053,15 @@ __device__ __forceinline__ void run_env(const d2d_cfg &c, const d2d_state &s, in
   D2D_STAMP(4);
   int newly = 0;
   if (do_ray) {
-#ifdef D2D_NO_UNROLL
-    const bool unroll = false;
-#else
-    const bool unroll = (g.smax == 10 && g.klo == 6);  // depth 80, scale 10
-#endif
     for (int i0 = 0; i0 < c.R; i0 += WAVE) {
       const int i = i0 + lane;
       const Ray ry = ray_setup(c, L, i, ncand, x0, y0, yaw0);
-      if (i0 == 0) {  // tiles have to be in LDS before the first sample reads / patches them
+      if (i0 == 0) {  // the tracker DMA and the tiles have to be in LDS before the first sample reads / patches them
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_wave_barrier();
+        wave_sync_lds();
         D2D_STAMP(5);
       }
-      if (unroll) ray_march<true>(c, g, L, ry, i < c.R, ncand, x0, y0, wt, ct, do_obs, dm);
-      else ray_march<false>(c, g, L, ry, i < c.R, ncand, x0, y0, wt, ct, do_obs, dm);
+      ray_march(c, g, L, ry, i < c.R, ncand, x0, y0, wt, ct, do_obs, dm);
     }
     wave_sync_lds();
     D2D_STAMP(6);
@@ -973,11 +1078,19 @@ __device__ __forceinline__ void run_env(const d2d_cfg &c, const d2d_state &s, in
     }
     if (lane == 0) s.newly[e] = newly;
     r.tracked += newly;
-  } else if (do_obs) {
+  } else if (do_obs || do_trk) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
   }
   D2D_STAMP(7);
+#ifndef D2D_ABL_NOTRK
+  if (do_trk) {  // two instantiations: a run-time choice between an LDS and a global pointer would become flat loads
+    if (g.kf_lds) st_tracker<true>(c, s, e, lane, g, L, r);
+    else st_tracker<false>(c, s, e, lane, g, L, r);
+  }
+#endif
+  D2D_STAMP(8);
+#ifndef D2D_ABL_NODYN
   if (do_dyn) {
     if (dyn_fast) {
       if (lane < N) dyn_apply<true>(c, s, e, lane, g, L, gt, dc);
@@ -985,64 +1098,78 @@ __device__ __forceinline__ void run_env(const d2d_cfg &c, const d2d_state &s, in
       for (int k = lane; k < N; k += WAVE) dyn_apply<false>(c, s, e, k, g, L, gt, dc);
     }
   }
-  D2D_STAMP(8);
-  if (do_trk) {  // two instantiations: a run-time choice between an LDS and a global pointer would become flat loads
-    if (g.kf_lds) st_tracker<true>(c, s, e, lane, g, L, r);
-    else st_tracker<false>(c, s, e, lane, g, L, r);
-  }
+#endif
   D2D_STAMP(9);
+#ifndef D2D_ABL_NOCOL
   if (do_col) st_collide(c, s, e, lane, L, probe_wall, r);
+#endif
   D2D_STAMP(10);
   D2D_STAMP(11);
-  if (do_obs) st_obs(c, s, e, lane, L, ct, r);
+#ifndef D2D_ABL_NOOBS
+  if (do_obs) {
+    wave_sync_lds();
+    st_obs(c, s, e, lane, L, r);
+  }
+#endif
   D2D_STAMP(12);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Specialisation for the reference's default geometry (utils.py:66-72: 500 x 500 px map, scale 10, depth 80,
+// FOV 90 => 50 x 50 cells, 50 rays, 33 x 33 crop; N <= 16 agents).  The kernel is bound by instruction issue
+// and by SGPR pressure: every field of the by-value config is a live scalar the compiler cannot
+// rematerialise, and past ~100 of them it spills to VGPR lanes (v_readlane on every use).  Overwriting the
+// kernel's own copy of the config with the literals the host has verified turns them into immediates:
+// constant-folded tile sizes and LDS offsets, no spills.  Any other config takes the generic instantiation.
+#define D2D_SPEC_NCAP 16
+__host__ __device__ inline bool spec_default_matches(const d2d_cfg &c) {
+  return c.N <= D2D_SPEC_NCAP && c.W == 50 && c.H == 50 && c.R == 50 && c.L == 33 && c.dt == 0.1 && c.scale == 10.0 &&
+         c.W_px == 500.0 && c.H_px == 500.0 && c.ray_off0 == -0x1.921fb54442d18p-1 && c.ray_dth == 0x1.015bf9217271ap-5 &&
+         c.depth == 80.0 && c.drone_radius == 10.0 && c.yaw_rate == 80.0 && c.max_acc == 40.0 && c.max_steps == 800.0 &&
+         c.sigma == 0.0;
+}
+
+__device__ __forceinline__ void spec_default_apply(d2d_cfg &c) {
+  c.W = 50; c.H = 50; c.R = 50; c.L = 33;
+  c.dt = 0.1; c.scale = 10.0; c.W_px = 500.0; c.H_px = 500.0;
+  c.ray_off0 = -0x1.921fb54442d18p-1; c.ray_dth = 0x1.015bf9217271ap-5;
+  c.depth = 80.0; c.drone_radius = 10.0; c.yaw_rate = 80.0; c.max_acc = 40.0; c.max_steps = 800.0; c.sigma = 0.0;
 }
 
 extern __shared__ __attribute__((aligned(16))) char d2d_lds[];
 
-__global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK, D2D_MIN_WAVES) void k_stages(d2d_cfg c, d2d_state s, uint32_t stages) {
+template <int SPEC>
+__global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK, D2D_MIN_WAVES) void k_stages(d2d_cfg c_in, d2d_state s, uint32_t stages,
+                                                                                 const double *pin, unsigned char *coll_out) {
+  d2d_cfg c = c_in;
+  if (SPEC == 1) spec_default_apply(c);
   // wave-uniform by construction; readfirstlane tells the compiler, so every per-env base pointer and LDS
   // base lives in SGPRs and loads take the scalar-base + 32-bit-offset form
-  const int lane = threadIdx.x & (WAVE - 1), wpb = blockDim.x / WAVE;
+  const int lane = threadIdx.x & (WAVE - 1), wpb = (SPEC == 1) ? WAVES_PER_BLOCK : (int)(blockDim.x / WAVE);
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);
   const int e = blockIdx.x * wpb + wv;
   if (e >= c.B) return;
-  const Geom g = make_geom(c, wpb);
+  const Geom g = make_geom(c, wpb, SPEC == 1 ? D2D_SPEC_NCAP : 0);
   const LdsView L = carve(d2d_lds + (size_t)wv * g.wave_bytes, g, c.L);
   EnvRegs r;
 #ifdef D2D_STAMPS
   if (d2d_stamp_buf && lane == 0) d2d_stamp_buf[(size_t)e * 16 + 0] = __builtin_amdgcn_s_memtime();
 #endif
   load_regs(s, e, r);
-  run_env(c, s, e, lane, stages, g, L, s.action[e], r);
-  if (lane == 0) store_regs(s, e, r);
-  D2D_STAMP(13);
-}
-
-// `nsteps` fused steps per launch; the env's scalar state stays in registers between steps
-__global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK) void k_rollout(d2d_cfg c, d2d_state s, int nsteps,
-                                                                   const double *actions, const double *pin,
-                                                                   unsigned char *coll_out) {
-  // wave-uniform by construction; readfirstlane tells the compiler, so every per-env base pointer and LDS
-  // base lives in SGPRs and loads take the scalar-base + 32-bit-offset form
-  const int lane = threadIdx.x & (WAVE - 1), wpb = blockDim.x / WAVE;
-  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);
-  const int e = blockIdx.x * wpb + wv;
-  if (e >= c.B) return;
-  const Geom g = make_geom(c, wpb);
-  const LdsView L = carve(d2d_lds + (size_t)wv * g.wave_bytes, g, c.L);
-  EnvRegs r;
-  load_regs(s, e, r);
-  for (int t = 0; t < nsteps; ++t) {
-    if (pin) {
-      r.x = pin[(size_t)e * 2];
-      r.y = pin[(size_t)e * 2 + 1];
-    }
-    run_env(c, s, e, lane, D2D_ST_ALL, g, L, actions[(size_t)t * c.B + e], r);
-    wave_sync_global();  // the next step re-reads grid cells / records other lanes of this wave wrote
-    if (coll_out && lane == 0) coll_out[(size_t)t * c.B + e] = s.flags[(size_t)e * 4 + D2D_F_COLLISION];
+#ifdef D2D_NO_PIN
+  pin = nullptr;
+  coll_out = nullptr;
+#endif
+  if (pin) {  // d2d_rollout: env.drone.x = x; env.drone.y = y before the step
+    r.x = pin[(size_t)e * 2];
+    r.y = pin[(size_t)e * 2 + 1];
   }
-  if (lane == 0) store_regs(s, e, r);
+  run_env(c, s, e, lane, stages, g, L, s.action[e], r);
+  if (lane == 0) {
+    store_regs(s, e, r);
+    if (coll_out) coll_out[e] = s.flags[(size_t)e * 4 + D2D_F_COLLISION];
+  }
+  D2D_STAMP(13);
 }
 
 // reset(): masked copy of the snapshot over the live state, one wave per env
@@ -1127,19 +1254,31 @@ int check(const d2d_cfg *c, const d2d_state *s) {
   return 0;
 }
 
-int launch_stages(const d2d_cfg *c, const d2d_state *s, uint32_t stages, void *stream) {
+int launch_stages(const d2d_cfg *c, const d2d_state *s, uint32_t stages, void *stream, const double *pin = nullptr,
+                  unsigned char *coll_out = nullptr) {
   int rc = check(c, s);
   if (rc) return rc;
   if (!s->action && (stages & D2D_ST_CONTROL)) return fail(-1, "null action");
   if ((stages & D2D_ST_CONTROL) && c->planner_mode == D2D_PLANNER_EXTERNAL && (!s->plan_ok || !s->wp_valid || !s->wp))
     return fail(-1, "external planner mode needs plan_ok / wp_valid / wp");
   if (c->B == 0) return 0;
-  const int wpb = pick_wpb(*c);
-  const Geom g = make_geom(*c, wpb);
-  const dim3 grid((c->B + wpb - 1) / wpb), block(WAVE * wpb);
   d2d_state st = *s;
   if (!st.action) st.action = (const double *)st.drone;  // never dereferenced meaningfully without CONTROL
-  hipLaunchKernelGGL(k_stages, grid, block, (size_t)g.wave_bytes * wpb, (hipStream_t)stream, *c, st, stages);
+#ifndef D2D_NO_SPEC
+  if (spec_default_matches(*c)) {
+    const Geom g = make_geom(*c, WAVES_PER_BLOCK, D2D_SPEC_NCAP);
+    const dim3 grid((c->B + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK), block(WAVE * WAVES_PER_BLOCK);
+    hipLaunchKernelGGL(k_stages<1>, grid, block, (size_t)g.wave_bytes * WAVES_PER_BLOCK, (hipStream_t)stream, *c, st,
+                       stages, pin, coll_out);
+  } else
+#endif
+  {
+    const int wpb = pick_wpb(*c);
+    const Geom g = make_geom(*c, wpb);
+    const dim3 grid((c->B + wpb - 1) / wpb), block(WAVE * wpb);
+    hipLaunchKernelGGL(k_stages<0>, grid, block, (size_t)g.wave_bytes * wpb, (hipStream_t)stream, *c, st, stages, pin,
+                       coll_out);
+  }
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return fail(-3, hipGetErrorString(err));
   return 0;
@@ -1169,19 +1308,17 @@ int d2d_act(const d2d_cfg *c, const d2d_state *s, void *stream) { return launch_
 
 int d2d_rollout(const d2d_cfg *c, const d2d_state *s, int32_t nsteps, const double *actions, const double *pin,
                 uint8_t *coll_out, void *stream) {
+  // nsteps fused steps queued back to back on the stream (one d2d_step-sized launch each, ~40 us of GPU work
+  // against ~5 us of launch cost, so a device-side step loop buys nothing and costs registers)
   int rc = check(c, s);
   if (rc) return rc;
   if (!actions || nsteps < 0) return fail(-1, "rollout: bad arguments");
-  if (c->planner_mode == D2D_PLANNER_EXTERNAL && (!s->plan_ok || !s->wp_valid || !s->wp))
-    return fail(-1, "external planner mode needs plan_ok / wp_valid / wp");
-  if (c->B == 0 || nsteps == 0) return 0;
-  const int wpb = pick_wpb(*c);
-  const Geom g = make_geom(*c, wpb);
-  const dim3 grid((c->B + wpb - 1) / wpb), block(WAVE * wpb);
-  hipLaunchKernelGGL(k_rollout, grid, block, (size_t)g.wave_bytes * wpb, (hipStream_t)stream, *c, *s,
-                     (int)nsteps, actions, pin, coll_out);
-  hipError_t err = hipGetLastError();
-  if (err != hipSuccess) return fail(-3, hipGetErrorString(err));
+  d2d_state st = *s;
+  for (int32_t t = 0; t < nsteps; ++t) {
+    st.action = actions + (size_t)t * c->B;
+    rc = launch_stages(c, &st, D2D_ST_ALL, stream, pin, coll_out ? coll_out + (size_t)t * c->B : nullptr);
+    if (rc) return rc;
+  }
   return 0;
 }
 

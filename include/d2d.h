@@ -184,8 +184,8 @@ int d2d_act(const d2d_cfg *cfg, const d2d_state *st, void *stream);
 /* Any subset of stages (D2D_ST_* bits) in reference order, one launch: per-stage profiling. */
 int d2d_run_stages(const d2d_cfg *cfg, const d2d_state *st, uint32_t stages, void *stream);
 
-/* `nsteps` consecutive fused steps in ONE launch, env-resident in registers/LDS between steps:
- * the reference's inner loops that call step() back to back with host-independent actions
+/* `nsteps` consecutive fused steps queued back to back on the stream by ONE call (no host round trip
+ * between them): the reference's inner loops that call step() back to back with host-independent actions
  * (glob_survivability_calculator.py:31-37).  actions: [nsteps][B]; optional pin: [B][2] drone
  * position forced before every step (env.drone.x = x; env.drone.y = y), or NULL;
  * coll_out: [nsteps][B] uint8 collision flag per step, or NULL. */

@@ -302,7 +302,8 @@ static void kf_update(env_view *v, int k, int has_z, double zx, double zy) {
       /* S2 = Sigma_z + H Sigma H^T ; K = Sigma H^T inv(S2) ; mu += K (z - H mu) ; Sigma = (I - K H) Sigma */
       double a = c->sigma + S[0], b = S[1], cc = S[4], d = c->sigma + S[5];
       double det = a * d - b * cc;
-      double i00 = d / det, i01 = -b / det, i10 = -cc / det, i11 = a / det;
+      double idet = 1.0 / det;
+      double i00 = d * idet, i01 = -b * idet, i10 = -cc * idet, i11 = a * idet;
       double K[8];
       for (int i = 0; i < 4; ++i) {
         K[2 * i] = S[4 * i] * i00 + S[4 * i + 1] * i10;
