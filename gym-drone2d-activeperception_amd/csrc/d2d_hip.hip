@@ -23,6 +23,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <type_traits>
 
 #include "../../include/d2d.h"
 
@@ -209,7 +210,7 @@ struct CellDiv {
   int s;
   __device__ __forceinline__ explicit CellDiv(double scale) : inv(1.0f / (float)scale), s((int)scale) {}
   __device__ __forceinline__ int operator()(double v) const {
-    const int vi = (int)v;  // truncation == floor for v >= 0
+    const int vi = __double2int_rz(v);  // truncation == floor for v >= 0; saturates / 0 for wild or NaN inputs
     int q = (int)((float)vi * inv);
     const int r = vi - q * s;
     q += (r >= s) ? 1 : 0;
@@ -598,7 +599,8 @@ __device__ __forceinline__ void ray_march(const d2d_cfg &c, const Geom &g, const
   const double c1x = L.cx[q1], c1y = L.cy[q1], c1r2 = has1 ? L.cr2[q1] : -1.0;
   const int c1i = L.cidx[q1];
   const unsigned int rest = mask_path ? (ry.cmask & (ry.cmask - 1u)) : 0u;
-  auto sample = [&](int k) {
+  auto sample = [&](auto far_tag) {
+    constexpr bool FAR = decltype(far_tag)::value;
     // exact circle tests (utils.py:658-662): every candidate that can matter, no early-out among agents
     bool any = false;
     {
@@ -627,14 +629,14 @@ __device__ __forceinline__ void ray_march(const d2d_cfg &c, const Geom &g, const
       }
     }
     // The cell of this sample and its ground-truth value from the LDS tile.  Unconditional and clamped (a
-    // live sample always lies inside the tile: the previous sample was nearer than `depth`); it must not
-    // become a select between an LDS and a global pointer (flat load + vmcnt(0) wait per sample).
-    const double xc = alive ? x : x0, yc = alive ? y : y0;
-    const int ci = cell(xc), cj = cell(yc);
+    // live sample always lies inside the tile: the previous sample was nearer than `depth`; a dead lane's
+    // garbage position just reads some tile byte that is then ignored); it must not become a select between
+    // an LDS and a global pointer (flat load + vmcnt(0) wait per sample).
+    const int ci = cell(x), cj = cell(y);
     const int wr = min(max(ci - wt.i0, 0), wt.rows - 1), wq = min(max(cj - wt.j0, 0), wt.cols - 1);
     const unsigned char wall = gtw[wt.byte_index(wr, wq)];
     bool far = false;
-    if (k > klo) far = ((x - x0) * (x - x0) + (y - y0) * (y - y0) >= depth2);
+    if (FAR) far = ((x - x0) * (x - x0) + (y - y0) * (y - y0) >= depth2);
     const bool stop = (wall == D2D_OCCUPIED) || far;
     const bool write = alive && !any && (!stop || wall == D2D_OCCUPIED);
     if (write) {
@@ -642,8 +644,8 @@ __device__ __forceinline__ void ray_march(const d2d_cfg &c, const Geom &g, const
 #ifndef D2D_ABL_NOSTORE
       dm[ci * H + cj] = v;
 #endif
-      const int pr = ci - ct.i0, pq = cj - ct.j0;  // keep the observation tile in step with the map
-      if (patch && pr >= 0 && pr < ct.rows && pq >= 0 && pq < ct.cols) dmt[ct.byte_index(pr, pq)] = v;
+      const unsigned int pr = (unsigned int)(ci - ct.i0), pq = (unsigned int)(cj - ct.j0);  // observation tile in step
+      if (patch && pr < (unsigned int)ct.rows && pq < (unsigned int)ct.cols) dmt[pr * ct.cols + pq] = v;
     }
     alive = alive && !any && !stop;
     x = x + ry.xs;
@@ -651,7 +653,10 @@ __device__ __forceinline__ void ray_march(const d2d_cfg &c, const Geom &g, const
     alive = alive && (0.0 < x && x < c.W_px && 0.0 < y && y < c.H_px);
   };
 #ifndef D2D_ABL_NOMARCH
-  for (int k = 0; k < g.smax; ++k) sample(k);  // not unrolled: a 10x body overflows the instruction cache
+  // not unrolled (a 10x body overflows the instruction cache); samples 0..klo cannot be past `depth`
+  const int k1 = min(klo + 1, g.smax);
+  for (int k = 0; k < k1; ++k) sample(std::false_type{});
+  for (int k = k1; k < g.smax; ++k) sample(std::true_type{});
 #endif
 }
 
