@@ -91,6 +91,13 @@ class VecDrone2DEnv:
         self.state.wp_valid.copy_(torch.as_tensor(wp_valid, dtype=torch.uint8).reshape(self.num_envs))
         self.state.wp.copy_(torch.as_tensor(wp, dtype=torch.float64).reshape(self.num_envs, 6))
 
+    def set_noise(self, noise):
+        """Standard-normal draws [B, N, 2] for the measurements of this step (utils.py:605); required when
+        var_cam != 0 (the reference takes them from np.random in agent order)."""
+        n = torch.as_tensor(noise, dtype=torch.float64).reshape(self.num_envs, self.cfg.N, 2).to(self.device).contiguous()
+        self.state.noise = n
+        self._st.noise = n.data_ptr()
+
     def step(self, actions):
         """One fused Drone2DEnv2.step for every env.  Returns (obs, reward, done, info) of tensors."""
         self._set_action(actions)

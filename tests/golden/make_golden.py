@@ -234,11 +234,24 @@ def gen_rows():
     save('experiment_rows', d)
 
 
+def gen_flags():
+    """Terminal-flag branches of envs/drone_v2.py:222-231: freezing (steps >= max_flight_time / dt) and dead lock
+    (10 consecutive planning failures at zero velocity: the target sits inside the border wall)."""
+    p = make_params(planner='NoMove', agent_number=3, agent_radius=8, agent_max_speed=10, map_id=21, max_flight_time=2,
+                    init_pos=[250, 250])
+    save('freezing_nomove', run_trace(p, 25, actions=[0.25] * 25, stop_on_done=False))
+    p = make_params(planner='Primitive', gaze_method='LookAhead', agent_number=2, agent_radius=8, agent_max_speed=10, map_id=22,
+                    init_pos=[250, 250], target_list=[[4, 4]])
+    save('deadlock_primitive', run_trace(p, 14, policy='LookAhead', stop_on_done=False))
+
+
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == 'sweep':
         return gen_sweep()
     if len(sys.argv) > 1 and sys.argv[1] == 'rows':
         return gen_rows()
+    if len(sys.argv) > 1 and sys.argv[1] == 'flags':
+        return gen_flags()
     rng = np.random.RandomState(12345)
 
     # --- A. NoMove closed loop, BASELINE config-1/2 parameters, constant action (SURVEY section 4 KAT)
@@ -328,6 +341,7 @@ def main():
     save('static_maps', maps)
     gen_sweep()
     gen_rows()
+    gen_flags()
 
 
 if __name__ == '__main__':

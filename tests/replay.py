@@ -114,6 +114,7 @@ class Replay:
 TRACES_NOMOVE = ['nomove_n10_const', 'nomove_n10_rand_map0', 'nomove_n10_rand_map2', 'nomove_n10_rand_map3',
                  'nomove_n10_rand_map7', 'nomove_teleport_structured', 'surv_pinned_360', 'nomove_obstacle_map',
                  'nomove_shaped_map', 'nomove_random_map_n172', 'nomove_pillars_randr', 'nomove_slow_agents',
-                 'nomove_big_map']
-TRACES_PLANNED = ['readme_oxford_primitive', 'lookahead_primitive_n30_map0', 'lookahead_primitive_n30_map3']
+                 'nomove_big_map', 'freezing_nomove']
+TRACES_PLANNED = ['readme_oxford_primitive', 'lookahead_primitive_n30_map0', 'lookahead_primitive_n30_map3',
+                  'deadlock_primitive']
 ALL_TRACES = TRACES_NOMOVE + TRACES_PLANNED

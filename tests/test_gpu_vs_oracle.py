@@ -49,6 +49,12 @@ CASES = [
          drone_view_depth=120, drone_view_range=200, init_pos=[420, 400], target_list=[[900, 700], [100, 100]]),
     dict(B=8, T=30, agent_number=6, agent_radius=12, agent_max_speed=4, map_id=11),
     dict(B=4, T=15, agent_number=0, agent_radius=10, agent_max_speed=20, map_id=2),
+    # 260 x 260 cells: no LDS coverage bitmap (loop fallback), 260 rays = 5 lane passes, wide view
+    dict(B=2, T=6, agent_number=24, agent_radius=22, agent_max_speed=60, map_id=4, map_size=[2600, 2600],
+         drone_view_depth=150, drone_view_range=170, init_pos=[1300, 1200], target_list=[[2500, 2500]]),
+    # big agents: dynamic blocks of 5 x 5 / 7 x 7 cells (generic dyn path), scale 20
+    dict(B=5, T=20, agent_number=9, agent_radius=45, agent_max_speed=50, map_id=8, map_scale=20, map_size=[1000, 1000],
+         init_pos=[500, 480], target_list=[[900, 900]]),
 ]
 
 
@@ -136,3 +142,18 @@ def test_full_size_properties(pkg, hip):
     env.reset()
     for k in ('agents', 'gt', 'dmap', 'drone', 'counters'):
         assert torch.equal(a[k], env.state.t[k])
+
+
+def test_measurement_noise_input(pkg, hip, oracle):
+    """var_cam != 0: the host supplies the normal draws; device and oracle agree bit for bit."""
+    B, T = 12, 25
+    dev, ref = _pair(pkg, hip, oracle, B, agent_number=14, agent_radius=12, agent_max_speed=30, map_id=31, var_cam=2)
+    rng = np.random.RandomState(5)
+    for t in range(T):
+        a = rng.uniform(-1, 1, B)
+        z = rng.randn(B, dev.N, 2)
+        for env in (dev, ref):
+            env.set_noise(z)
+            env.step(a)
+        _assert_same(dev, ref, f'step {t + 1}')
+    assert int(dev.state.active.sum()) > 0
