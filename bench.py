@@ -101,10 +101,16 @@ def main():
     ap.add_argument('--warmup', type=int, default=50)
     ap.add_argument('--envs', type=int, default=4096, help='envs per GPU')
     ap.add_argument('--agents', type=int, default=10)
+    ap.add_argument('--static-map', default='maps/empty_map.npy', help='exploration only: other BASELINE configs')
+    ap.add_argument('--agent-speed', type=int, default=20)
+    ap.add_argument('--agent-radius', type=int, default=15)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--workers', type=int, default=min(8, os.cpu_count() or 1),
                     help='host processes building the worlds (forked BEFORE the GPU is touched; 0 = in-process, '
                          'use 0 under rocprofv3)')
+    ap.add_argument('--dist-backend', default='nccl', choices=['nccl', 'gloo'],
+                    help='gloo + --single-device: dry run of the multi-rank path on a 1-GPU box')
+    ap.add_argument('--single-device', action='store_true', help='every rank uses cuda:0 (dry run only)')
     ap.add_argument('--mode', default='launch', choices=['launch', 'graph'],
                     help='launch: one d2d_step launch per step; graph: the K launches captured in one hipGraph')
     args = ap.parse_args()
@@ -117,17 +123,23 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     B, K, Wm = args.envs, args.steps, args.warmup
-    params = pkg.Params(planner='Primitive', gaze_method='Oxford', agent_number=args.agents, agent_radius=15,
-                        agent_max_speed=20, drone_max_speed=40, map_id=1)
+    params = pkg.Params(planner='Primitive', gaze_method='Oxford', agent_number=args.agents, agent_radius=args.agent_radius,
+                        agent_max_speed=args.agent_speed, drone_max_speed=40, map_id=1, static_map=args.static_map)
     # host world construction (the reference's __init__, seeded per global env id) before any GPU call
     worlds = vec_env.build_worlds(params, B, env_offset=rank * B, workers=args.workers)
+    if args.single_device:
+        local = 0
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         torch.cuda.set_device(local)
-        dist.init_process_group('nccl', device_id=torch.device(f'cuda:{local}'))
+        if args.dist_backend == 'nccl':     # 'nccl' IS RCCL on ROCm: collectives over xGMI
+            dist.init_process_group('nccl', device_id=torch.device(f'cuda:{local}'))
+        else:
+            dist.init_process_group('gloo')
     device = f'cuda:{local}'
     torch.cuda.set_device(local)
+    coll_dev = device if args.dist_backend == 'nccl' else 'cpu'
 
     env = vec_env.VecDrone2DEnv(params, B, device=device, planner='external', env_offset=rank * B, worlds=worlds)
     T = K + Wm
@@ -186,9 +198,10 @@ def main():
     # episode statistics: the only exchange of the path (RCCL all_gather over xGMI), once per run
     stats = env.episode_stats()
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+        stats = stats.to(coll_dev)
         allstats = [torch.empty_like(stats) for _ in range(world)]
         dist.all_gather(allstats, stats)
         stats = torch.cat(allstats)

@@ -1126,9 +1126,10 @@ __device__ __forceinline__ void run_env(const d2d_cfg &c, const d2d_state &s, in
 // rematerialise, and past ~100 of them it spills to VGPR lanes (v_readlane on every use).  Overwriting the
 // kernel's own copy of the config with the literals the host has verified turns them into immediates:
 // constant-folded tile sizes and LDS offsets, no spills.  Any other config takes the generic instantiation.
-#define D2D_SPEC_NCAP 16
+// SPEC 1: N <= 16 agent slots, SPEC 2: N <= 32 (the default map plus the 14 obstacle_map agents)
+__host__ __device__ constexpr int spec_ncap(int spec) { return spec == 1 ? 16 : (spec == 2 ? 32 : 0); }
 __host__ __device__ inline bool spec_default_matches(const d2d_cfg &c) {
-  return c.N <= D2D_SPEC_NCAP && c.W == 50 && c.H == 50 && c.R == 50 && c.L == 33 && c.dt == 0.1 && c.scale == 10.0 &&
+  return c.N <= spec_ncap(2) && c.W == 50 && c.H == 50 && c.R == 50 && c.L == 33 && c.dt == 0.1 && c.scale == 10.0 &&
          c.W_px == 500.0 && c.H_px == 500.0 && c.ray_off0 == -0x1.921fb54442d18p-1 && c.ray_dth == 0x1.015bf9217271ap-5 &&
          c.depth == 80.0 && c.drone_radius == 10.0 && c.yaw_rate == 80.0 && c.max_acc == 40.0 && c.max_steps == 800.0 &&
          c.sigma == 0.0;
@@ -1147,14 +1148,14 @@ template <int SPEC>
 __global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK, D2D_MIN_WAVES) void k_stages(d2d_cfg c_in, d2d_state s, uint32_t stages,
                                                                                  const double *pin, unsigned char *coll_out) {
   d2d_cfg c = c_in;
-  if (SPEC == 1) spec_default_apply(c);
+  if (SPEC != 0) spec_default_apply(c);
   // wave-uniform by construction; readfirstlane tells the compiler, so every per-env base pointer and LDS
   // base lives in SGPRs and loads take the scalar-base + 32-bit-offset form
-  const int lane = threadIdx.x & (WAVE - 1), wpb = (SPEC == 1) ? WAVES_PER_BLOCK : (int)(blockDim.x / WAVE);
+  const int lane = threadIdx.x & (WAVE - 1), wpb = (SPEC != 0) ? WAVES_PER_BLOCK : (int)(blockDim.x / WAVE);
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);
   const int e = blockIdx.x * wpb + wv;
   if (e >= c.B) return;
-  const Geom g = make_geom(c, wpb, SPEC == 1 ? D2D_SPEC_NCAP : 0);
+  const Geom g = make_geom(c, wpb, spec_ncap(SPEC));
   const LdsView L = carve(d2d_lds + (size_t)wv * g.wave_bytes, g, c.L);
   EnvRegs r;
 #ifdef D2D_STAMPS
@@ -1271,10 +1272,12 @@ int launch_stages(const d2d_cfg *c, const d2d_state *s, uint32_t stages, void *s
   if (!st.action) st.action = (const double *)st.drone;  // never dereferenced meaningfully without CONTROL
 #ifndef D2D_NO_SPEC
   if (spec_default_matches(*c)) {
-    const Geom g = make_geom(*c, WAVES_PER_BLOCK, D2D_SPEC_NCAP);
+    const int spec = c->N <= spec_ncap(1) ? 1 : 2;
+    const Geom g = make_geom(*c, WAVES_PER_BLOCK, spec_ncap(spec));
     const dim3 grid((c->B + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK), block(WAVE * WAVES_PER_BLOCK);
-    hipLaunchKernelGGL(k_stages<1>, grid, block, (size_t)g.wave_bytes * WAVES_PER_BLOCK, (hipStream_t)stream, *c, st,
-                       stages, pin, coll_out);
+    const size_t lds = (size_t)g.wave_bytes * WAVES_PER_BLOCK;
+    if (spec == 1) hipLaunchKernelGGL(k_stages<1>, grid, block, lds, (hipStream_t)stream, *c, st, stages, pin, coll_out);
+    else hipLaunchKernelGGL(k_stages<2>, grid, block, lds, (hipStream_t)stream, *c, st, stages, pin, coll_out);
   } else
 #endif
   {
