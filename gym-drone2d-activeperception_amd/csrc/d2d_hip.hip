@@ -580,6 +580,9 @@ __device__ __forceinline__ Ray ray_setup(const d2d_cfg &c, const LdsView &L, int
 // decisions are predicated on `alive` instead of steering control flow, so consecutive samples' LDS
 // lookups overlap and no lane waits for the slowest ray.  `dist >= depth^2` is only evaluated for samples
 // k > klo (earlier ones are nearer than `depth` for any slope).
+// GENERAL: some ray of the wave has more than one candidate (or the env more than 32): the per-sample LDS
+// candidate loops are compiled in.  The common instantiation tests only the register-held first candidate.
+template <bool GENERAL>
 __device__ __forceinline__ void ray_march(const d2d_cfg &c, const Geom &g, const LdsView &L, const Ray &ry, bool active,
                                           int ncand, double x0, double y0, const Tile &wt, const Tile &ct, bool patch,
                                           unsigned char *__restrict__ dm) {
@@ -608,7 +611,7 @@ __device__ __forceinline__ void ray_march(const d2d_cfg &c, const Geom &g, const
       any = alive && (dx * dx + dy * dy <= c1r2);
       if (any) L.hit[c1i] = 1;
     }
-    if (mask_path) {
+    if (GENERAL && mask_path) {
       unsigned int m = alive ? rest : 0u;
       while (m) {
         const int q = __ffs((int)m) - 1;
@@ -619,7 +622,7 @@ __device__ __forceinline__ void ray_march(const d2d_cfg &c, const Geom &g, const
           any = true;
         }
       }
-    } else if (alive) {
+    } else if (GENERAL && alive) {
       for (int q = 0; q < ncand; ++q) {
         const double dx = L.cx[q] - x, dy = L.cy[q] - y;
         if (dx * dx + dy * dy <= L.cr2[q]) {
@@ -655,7 +658,9 @@ __device__ __forceinline__ void ray_march(const d2d_cfg &c, const Geom &g, const
 #ifndef D2D_ABL_NOMARCH
   // not unrolled (a 10x body overflows the instruction cache); samples 0..klo cannot be past `depth`
   const int k1 = min(klo + 1, g.smax);
+#pragma unroll 1
   for (int k = 0; k < k1; ++k) sample(std::false_type{});
+#pragma unroll 1
   for (int k = k1; k < g.smax; ++k) sample(std::true_type{});
 #endif
 }
@@ -1066,7 +1071,9 @@ __device__ __forceinline__ void run_env(const d2d_cfg &c, const d2d_state &s, in
         wave_sync_lds();
         D2D_STAMP(5);
       }
-      ray_march(c, g, L, ry, i < c.R, ncand, x0, y0, wt, ct, do_obs, dm);
+      const bool general = ncand > 32 || __any((ry.cmask & (ry.cmask - 1u)) != 0u);
+      if (general) ray_march<true>(c, g, L, ry, i < c.R, ncand, x0, y0, wt, ct, do_obs, dm);
+      else ray_march<false>(c, g, L, ry, i < c.R, ncand, x0, y0, wt, ct, do_obs, dm);
     }
     wave_sync_lds();
     D2D_STAMP(6);
