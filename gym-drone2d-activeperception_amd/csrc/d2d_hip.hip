@@ -55,11 +55,12 @@ namespace {
 // small exact helpers
 // ------------------------------------------------------------------------------------------------
 
-// Exact fmod(a, b) for a >= 0, b > 0 (a / b far below 2^53): the true remainder is representable, so
-// once the quotient is right the fused multiply-add returns it without rounding.  No loop: a wild
-// input (inf / NaN / huge yaw written by a caller) must not be able to hang a wave.
-__device__ __forceinline__ double fmod_pos(double a, double b) {
-  double n = trunc(a / b);
+// Exact fmod(a, b) for a >= 0, b > 0 (a / b far below 2^52): the true remainder is representable, so once
+// the quotient is right the fused multiply-add returns it without rounding.  The quotient estimate uses a
+// multiplication by 1/b (no fp64 division); it can be off by one, which the two fix-ups absorb.  No loop: a
+// wild input (inf / NaN / huge yaw written by a caller) must not be able to hang a wave.
+__device__ __forceinline__ double fmod_pos(double a, double b, double inv_b) {
+  double n = trunc(a * inv_b);
   double m = __builtin_fma(-n, b, a);
   if (m < 0.0) m = __builtin_fma(-(n - 1.0), b, a);
   else if (m >= b) m = __builtin_fma(-(n + 1.0), b, a);
@@ -69,7 +70,7 @@ __device__ __forceinline__ double fmod_pos(double a, double b) {
 // Python float `a % 360.0` (utils.py:743): fmod, then the sign fix-up with one rounded add.
 __device__ __forceinline__ double py_mod360(double a) {
   const double m360 = 360.0;
-  double m = copysign(fmod_pos(fabs(a), m360), a);
+  double m = copysign(fmod_pos(fabs(a), m360, 0x1.6c16c16c16c17p-9 /* 1/360 */), a);
   if (m != 0.0) {
     if (m < 0.0) m += m360;
   } else {
@@ -490,7 +491,7 @@ __device__ __forceinline__ void kf_stage(const d2d_cfg &c, const d2d_state &s, i
 // utils.py:612-618
 __device__ __forceinline__ double positive_angle(double a) {
   const double two_pi = 0x1.921fb54442d18p+2;  // math.pi * 2
-  a = copysign(fmod_pos(fabs(a), two_pi), a);
+  a = copysign(fmod_pos(fabs(a), two_pi, 0x1.45f306dc9c883p-3 /* 1/(2 pi) */), a);
   if (a < 0.0) a += two_pi;
   return a;
 }
@@ -680,7 +681,7 @@ __device__ __forceinline__ bool dyn_covered_loop(const LdsView &L, int N, int i,
 // without changing the outcome -- no clear/set ordering, no memory fence.  Coverage comes from an LDS
 // bitmap every agent ORs its new block into.
 struct DynCells {  // the common case (blocks of at most 3 x 3 cells), reduced to what the update needs
-  unsigned int pdyn;   // bit q: previous-block cell q holds DYNAMIC
+  unsigned int pclr;   // bit q: previous-block cell q holds DYNAMIC and is not inside this agent's own new block
   unsigned int nfree;  // bit q: new-block cell q is neither static nor already DYNAMIC
 };
 
@@ -698,6 +699,15 @@ __device__ __forceinline__ void dyn_bitmap(const d2d_cfg &c, int lane, const Geo
         atomicOr(&L.bm[bit >> 5], 1u << (bit & 31));
       }
   }
+}
+
+// 3 x 3 cells (bit q = (di + 1) * 3 + (dj + 1)) of a block of half-width u in {0, 1} that lie inside the grid
+__device__ __forceinline__ unsigned int block_valid9(int cx, int cy, int u, int W, int H) {
+  if (u == 0) return 0x010u;
+  unsigned int rows = 0x2u | (cx - 1 >= 0 ? 0x1u : 0u) | (cx + 1 < W ? 0x4u : 0u);
+  unsigned int cols = 0x2u | (cy - 1 >= 0 ? 0x1u : 0u) | (cy + 1 < H ? 0x4u : 0u);
+  const unsigned int r9 = ((rows & 1u) ? 0x007u : 0u) | ((rows & 2u) ? 0x038u : 0u) | ((rows & 4u) ? 0x1C0u : 0u);
+  return r9 & (cols | (cols << 3) | (cols << 6));
 }
 
 __device__ __forceinline__ void dyn_load(const d2d_cfg &c, const unsigned char *__restrict__ gt, int k, const LdsView &L,
@@ -726,17 +736,25 @@ __device__ __forceinline__ void dyn_load(const d2d_cfg &c, const unsigned char *
       nv[q] = gt[min(max(ncx + di, 0), W - 1) * H + min(max(ncy + dj, 0), H - 1)];
     }
   }
-  dc.pdyn = 0;
-  dc.nfree = 0;
+  unsigned int pdyn = 0, nfree = 0;
 #pragma unroll
   for (int q = 0; q < 9; ++q) {
-    const int di = q / 3 - 1, dj = q % 3 - 1;
-    const int i = pcx + di, j = pcy + dj, i2 = ncx + di, j2 = ncy + dj;
-    const bool ok = small && abs(di) <= pu && abs(dj) <= pu && i >= 0 && i < W && j >= 0 && j < H;
-    const bool ok2 = small && abs(di) <= nu && abs(dj) <= nu && i2 >= 0 && i2 < W && j2 >= 0 && j2 < H;
-    dc.pdyn |= (ok && pv[q] == D2D_DYNAMIC) ? (1u << q) : 0u;
-    dc.nfree |= (ok2 && nv[q] != D2D_OCCUPIED && nv[q] != D2D_DYNAMIC) ? (1u << q) : 0u;
+    pdyn |= (pv[q] == D2D_DYNAMIC) ? (1u << q) : 0u;
+    nfree |= (nv[q] != D2D_OCCUPIED && nv[q] != D2D_DYNAMIC) ? (1u << q) : 0u;
   }
+  // previous cells inside this agent's own new block stay DYNAMIC whatever the others do: only the rest
+  // (none unless the agent changed cell) needs the coverage bitmap
+  unsigned int own = 0;
+  {
+    const int dx = ncx - pcx, dy = ncy - pcy;  // prev cell (di, dj) is in the new block iff |di - dx| <= nu, |dj - dy| <= nu
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+      const int di = q / 3 - 1, dj = q % 3 - 1;
+      own |= (abs(di - dx) <= nu && abs(dj - dy) <= nu) ? (1u << q) : 0u;
+    }
+  }
+  dc.pclr = small ? (pdyn & block_valid9(pcx, pcy, pu, W, H) & ~own) : 0u;
+  dc.nfree = small ? (nfree & block_valid9(ncx, ncy, nu, W, H)) : 0u;
 }
 
 template <bool FAST>
@@ -751,18 +769,19 @@ __device__ __forceinline__ void dyn_apply(const d2d_cfg &c, const d2d_state &s, 
     return use_bm ? ((L.bm[bit >> 5] >> (bit & 31)) & 1u) != 0u : dyn_covered_loop(L, N, i, j);
   };
   if (FAST && pu <= 1 && nu <= 1) {
-    bool cov[9];
-#pragma unroll
-    for (int q = 0; q < 9; ++q) {  // coverage of the 9 previous cells: independent LDS reads, one wait
-      const int i = min(max(pcx + q / 3 - 1, 0), W - 1), j = min(max(pcy + q % 3 - 1, 0), H - 1);
-      const int bit = i * H + j;
-      cov[q] = use_bm ? ((L.bm[bit >> 5] >> (bit & 31)) & 1u) != 0u : dyn_covered_loop(L, N, i, j);
+    // only set bits cost anything: none for an agent that stayed in its cell, a handful when it moved on
+    unsigned int m = dc.pclr;
+    while (m) {
+      const int q = __ffs((int)m) - 1;
+      m &= m - 1;
+      const int i = pcx + q / 3 - 1, j = pcy + q % 3 - 1;
+      if (!covered(i, j)) gt[i * H + j] = D2D_UNOCCUPIED;
     }
-#pragma unroll
-    for (int q = 0; q < 9; ++q) {
-      const int di = q / 3 - 1, dj = q % 3 - 1;
-      if (((dc.pdyn >> q) & 1u) && !cov[q]) gt[(pcx + di) * H + (pcy + dj)] = D2D_UNOCCUPIED;
-      if ((dc.nfree >> q) & 1u) gt[(ncx + di) * H + (ncy + dj)] = D2D_DYNAMIC;
+    m = dc.nfree;
+    while (m) {
+      const int q = __ffs((int)m) - 1;
+      m &= m - 1;
+      gt[(ncx + q / 3 - 1) * H + (ncy + q % 3 - 1)] = D2D_DYNAMIC;
     }
   } else {
     const int i1 = min(pcx + pu + 1, W), j1 = min(pcy + pu + 1, H);
@@ -1048,7 +1067,7 @@ __device__ __forceinline__ void run_env(const d2d_cfg &c, const d2d_state &s, in
   const bool dyn_fast = do_dyn && N <= WAVE;
   if (do_dyn) dyn_bitmap(c, lane, g, L);
   DynCells dc;
-  dc.pdyn = dc.nfree = 0;
+  dc.pclr = dc.nfree = 0;
   if (dyn_fast && lane < N) dyn_load(c, gt, lane, L, dc);
 
   // ---------------- raycast: setup while batch 2 is in flight ----------------
