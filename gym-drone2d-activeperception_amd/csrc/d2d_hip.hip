@@ -1152,10 +1152,11 @@ __device__ __forceinline__ void run_env(const d2d_cfg &c, const d2d_state &s, in
 // rematerialise, and past ~100 of them it spills to VGPR lanes (v_readlane on every use).  Overwriting the
 // kernel's own copy of the config with the literals the host has verified turns them into immediates:
 // constant-folded tile sizes and LDS offsets, no spills.  Any other config takes the generic instantiation.
-// SPEC 1: N <= 16 agent slots, SPEC 2: N <= 32 (the default map plus the 14 obstacle_map agents)
+// SPEC 1: N <= 16 agent slots, SPEC 2: N <= 32 (the default map plus the 14 obstacle_map agents), SPEC 3: the
+// default geometry with any N (LDS capacity and waves per workgroup stay run-time values)
 __host__ __device__ constexpr int spec_ncap(int spec) { return spec == 1 ? 16 : (spec == 2 ? 32 : 0); }
 __host__ __device__ inline bool spec_default_matches(const d2d_cfg &c) {
-  return c.N <= spec_ncap(2) && c.W == 50 && c.H == 50 && c.R == 50 && c.L == 33 && c.dt == 0.1 && c.scale == 10.0 &&
+  return c.W == 50 && c.H == 50 && c.R == 50 && c.L == 33 && c.dt == 0.1 && c.scale == 10.0 &&
          c.W_px == 500.0 && c.H_px == 500.0 && c.ray_off0 == -0x1.921fb54442d18p-1 && c.ray_dth == 0x1.015bf9217271ap-5 &&
          c.depth == 80.0 && c.drone_radius == 10.0 && c.yaw_rate == 80.0 && c.max_acc == 40.0 && c.max_steps == 800.0 &&
          c.sigma == 0.0;
@@ -1177,7 +1178,7 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK, D2D_MIN_WAVES) void k_stages
   if (SPEC != 0) spec_default_apply(c);
   // wave-uniform by construction; readfirstlane tells the compiler, so every per-env base pointer and LDS
   // base lives in SGPRs and loads take the scalar-base + 32-bit-offset form
-  const int lane = threadIdx.x & (WAVE - 1), wpb = (SPEC != 0) ? WAVES_PER_BLOCK : (int)(blockDim.x / WAVE);
+  const int lane = threadIdx.x & (WAVE - 1), wpb = (SPEC == 1 || SPEC == 2) ? WAVES_PER_BLOCK : (int)(blockDim.x / WAVE);
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);
   const int e = blockIdx.x * wpb + wv;
   if (e >= c.B) return;
@@ -1297,7 +1298,13 @@ int launch_stages(const d2d_cfg *c, const d2d_state *s, uint32_t stages, void *s
   d2d_state st = *s;
   if (!st.action) st.action = (const double *)st.drone;  // never dereferenced meaningfully without CONTROL
 #ifndef D2D_NO_SPEC
-  if (spec_default_matches(*c)) {
+  if (spec_default_matches(*c) && c->N > spec_ncap(2)) {
+    const int wpb = pick_wpb(*c);
+    const Geom g = make_geom(*c, wpb);
+    const dim3 grid((c->B + wpb - 1) / wpb), block(WAVE * wpb);
+    hipLaunchKernelGGL(k_stages<3>, grid, block, (size_t)g.wave_bytes * wpb, (hipStream_t)stream, *c, st, stages, pin,
+                       coll_out);
+  } else if (spec_default_matches(*c)) {
     const int spec = c->N <= spec_ncap(1) ? 1 : 2;
     const Geom g = make_geom(*c, WAVES_PER_BLOCK, spec_ncap(spec));
     const dim3 grid((c->B + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK), block(WAVE * WAVES_PER_BLOCK);
