@@ -4,7 +4,7 @@
 set -u
 TAG=${1:-r01}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$ROOT/gpurun_out/$TAG
+OUT=$ROOT/gpurun_out/$TAG; rm -rf "$OUT"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 ARGS="--steps 300 --warmup 30 --no-cpu-baseline --workers 0 ${BENCH_ARGS:-}"
