@@ -11,6 +11,9 @@ Layout
   env.py         Drone2DEnv2: single-env gym facade (gym-2d-perception-v2) over VecDrone2DEnv
   planners.py    --planner plugin surface (traj_planner.py)
   gaze.py        --gaze_method plugin surface (yaw_planner.py)
+  batch.py       HostPluginBatch: B episodes with host plugins in lock-step on one device batch
+  sweeps.py      survivability sweeps (glob_survivability_calculator.py) on d2d_rollout
+  runner.py      Experiment: one episode -> the reference's CSV row (experiment.py)
   dist.py        env sharding across GPUs, RCCL gather of episode statistics
 
 The directory name is the one the build contract prescribes; because of the hyphens import it with

@@ -210,8 +210,9 @@ class DroneProxy:
 class Drone2DEnv2(_EnvBase):
     metadata = {'render.modes': []}
 
-    def __init__(self, params, device='cuda:0', backend=None):
+    def __init__(self, params, device='cuda:0', backend=None, _shared=None):
         self._device, self._backend = device, backend
+        self._shared = _shared            # (VecDrone2DEnv, index): this env is slot `index` of a shared batch (batch.py)
         self._build(params)
 
     # ------------------------------------------------------------------------------------------
@@ -222,11 +223,14 @@ class Drone2DEnv2(_EnvBase):
             raise NotImplementedError('motion_profile RVO is outside the accelerated hot path (SURVEY.md section 2)')
         if p.planner not in planner_list:
             raise KeyError(f'unknown planner {p.planner!r}; known: {sorted(planner_list)}')
-        self._device_nomove = (p.planner == 'NoMove')
-        self._vec = VecDrone2DEnv(p, 1, device=self._device, backend=self._backend,
-                                  planner='NoMove' if self._device_nomove else 'external')
+        self._device_nomove = (p.planner == 'NoMove') and self._shared is None
+        if self._shared is None:
+            self._vec, self._slot = VecDrone2DEnv(p, 1, device=self._device, backend=self._backend,
+                                                  planner='NoMove' if self._device_nomove else 'external'), 0
+        else:
+            self._vec, self._slot = self._shared
         self._backend = self._vec.backend
-        self._tracker_radius = self._vec.tracker_radius[0].numpy().copy()
+        self._tracker_radius = self._vec.tracker_radius[self._slot].numpy().copy()
         from . import host_init
         self._group = host_init.init_world(p)['group'] if self._vec.N else np.zeros(0, dtype=np.int64)
         self.dt = p.dt
@@ -262,10 +266,10 @@ class Drone2DEnv2(_EnvBase):
         s = self._vec.state
         for k in ('agents', 'agent_unit', 'gt', 'dmap', 'drone', 'target', 'counters', 'active', 'kf', 'kf_len',
                   'hit', 'flags', 'obs_local', 'obs_yaw', 'newly'):
-            self._mirror[k] = s.t[k][0].cpu().numpy().copy()
+            self._mirror[k] = s.t[k][self._slot].cpu().numpy().copy()
 
     def _push(self, field, arr):
-        self._vec.state.t[field][0].copy_(torch.from_numpy(np.ascontiguousarray(arr)))
+        self._vec.state.t[field][self._slot].copy_(torch.from_numpy(np.ascontiguousarray(arr)))
 
     def _info(self, col, dead, frz):
         return {'drone': self.drone, 'trajectory': self.planner.trajectory, 'state_machine': self.state_machine,
@@ -274,36 +278,32 @@ class Drone2DEnv2(_EnvBase):
 
     # ------------------------------------------------------------------------------------------
     def reset(self):
+        if self._shared is not None:
+            raise RuntimeError('reset the HostPluginBatch, not its slots')
         self._build(self.params)
         return {}
 
-    def step(self, a):
-        a_val = float(np.asarray(a, dtype=np.float64).ravel()[0])
-        vec = self._vec
-        if self._device_nomove:
-            vec.step(a_val)
-            self._pull()
-            self.planner.target = np.array([-1, -1, 0, 0])            # traj_planner.py:72
-        else:
-            vec.perceive()
-            self._pull()
-            # set_target as the device's state machine just did (drone_v2.py:160-163)
-            self.planner.target = np.array([self._mirror['target'][0], self._mirror['target'][1], 0., 0.])
-            _, swep_map = self.planner.replan_check(self.drone)        # drone_v2.py:194
-            ok = bool(self.planner.plan(self.drone, self.dt))          # drone_v2.py:197
-            tr = self.planner.trajectory
-            wp = np.zeros(6)
-            has_wp = len(tr) > 0
-            if has_wp:
-                wp[0:2] = np.asarray(tr.positions[0], dtype=np.float64).ravel()
-                wp[2:4] = np.asarray(tr.velocities[0], dtype=np.float64).ravel()
-                wp[4:6] = np.asarray(tr.accelerations[0], dtype=np.float64).ravel()
-                tr.pop()                                               # utils.py:739
-            tgt = np.asarray(self.planner.target, dtype=np.float64).ravel()
-            self._push('target', tgt[:2])                              # planners may move the target (NoMove does)
-            vec.set_plan([ok], [has_wp], wp[None])
-            vec.act(a_val)
-            self._pull()
+    def _plan_phase(self):
+        """Host planner plugin between the two device halves (drone_v2.py:194-197 + utils.py:733-739).  Returns
+        (plan_ok, has_waypoint, waypoint[6]) and pushes the planner's target to the device."""
+        # set_target as the device's state machine just did (drone_v2.py:160-163)
+        self.planner.target = np.array([self._mirror['target'][0], self._mirror['target'][1], 0., 0.])
+        _, swep_map = self.planner.replan_check(self.drone)            # drone_v2.py:194
+        ok = bool(self.planner.plan(self.drone, self.dt))              # drone_v2.py:197
+        tr = self.planner.trajectory
+        wp = np.zeros(6)
+        has_wp = len(tr) > 0
+        if has_wp:
+            wp[0:2] = np.asarray(tr.positions[0], dtype=np.float64).ravel()
+            wp[2:4] = np.asarray(tr.velocities[0], dtype=np.float64).ravel()
+            wp[4:6] = np.asarray(tr.accelerations[0], dtype=np.float64).ravel()
+            tr.pop()                                                   # utils.py:739
+        tgt = np.asarray(self.planner.target, dtype=np.float64).ravel()
+        self._push('target', tgt[:2])                                  # planners may move the target (NoMove does)
+        return ok, has_wp, wp
+
+    def _finish_step(self):
+        """Refresh the reference-visible attributes from the mirror and build the step's return value."""
         m = self._mirror
         c, f = m['counters'], m['flags']
         self.steps = int(c[A.C_STEPS])
@@ -318,6 +318,24 @@ class Drone2DEnv2(_EnvBase):
         state = {'local_map': m['obs_local'][None], 'swep_map': m['obs_local'][None],       # drone_v2.py:251-255
                  'yaw_angle': np.array([m['obs_yaw']], dtype=np.float32).flatten()}
         return state, 0, done, self.info
+
+    def step(self, a):
+        if self._shared is not None:
+            raise RuntimeError('this env is a slot of a HostPluginBatch: step the batch, not the slot')
+        a_val = float(np.asarray(a, dtype=np.float64).ravel()[0])
+        vec = self._vec
+        if self._device_nomove:
+            vec.step(a_val)
+            self._pull()
+            self.planner.target = np.array([-1, -1, 0, 0])            # traj_planner.py:72
+        else:
+            vec.perceive()
+            self._pull()
+            ok, has_wp, wp = self._plan_phase()
+            vec.set_plan([ok], [has_wp], wp[None])
+            vec.act(a_val)
+            self._pull()
+        return self._finish_step()
 
     def render(self, mode='human'):
         raise NotImplementedError('rendering (pygame) is outside the accelerated hot path')
