@@ -50,7 +50,8 @@ def survivability_batch(indices, position_step=60, T=24, device='cuda:0', backen
         pins += cells
     env = VecDrone2DEnv(plist[0], len(worlds), device=device, backend=backend, planner='NoMove', worlds=worlds)
     actions = torch.zeros((n_steps, len(worlds)), dtype=torch.float64, device=env.device)
-    coll = env.rollout(actions, pin=np.asarray(pins, dtype=np.float64), collisions=True)
+    coll = env.rollout(actions, pin=np.asarray(pins, dtype=np.float64), collisions=True,
+                       streams=2 if len(worlds) >= 1024 else 1)
     env.sync()
     hit = (coll == 2).T.reshape(len(plist), len(xs), len(ys), n_steps).cpu().numpy()
     # The reference files step k under int(t / 0.1) with t = np.arange(0, T, 0.1)[k] (:38-39).  That is not

@@ -106,6 +106,12 @@ def test_rollout_and_reset_on_device(pkg, hip, oracle):
     dev.sync()
     assert torch.equal(cd.cpu(), cr)
     _assert_same(dev, ref, 'after rollout')
+    # the same chain split over 3 independent streams (ragged sub-batches of 7 envs)
+    dev2, _ = _pair(pkg, hip, oracle, B, agent_number=20, agent_radius=10, agent_max_speed=40, map_id=5)
+    cd2 = dev2.rollout(acts, pin=pin, collisions=True, streams=3)
+    dev2.sync()
+    assert torch.equal(cd2.cpu(), cr)
+    _assert_same(dev2, ref, 'after 3-stream rollout')
     mask = torch.from_numpy((rng.rand(B) < 0.5).astype(np.uint8))
     dev.reset(mask)
     ref.reset(mask)
