@@ -7,7 +7,8 @@
 
 Workload (N=1): BASELINE.json configs[1] — 4096 batched envs x 10 agents, agent_radius=15, 50x50 grid,
 50 rays, env i = the reference world for map_id 1+i.  A "step" = one fused Drone2DEnv2.step over the
-whole batch (one d2d_step launch).  Gaze actions are fixed-seed U(-1,1) and the planner result is a
+whole batch (d2d_step launches: by default the batch is cut into 2 independent halves stepped on two
+free-running HIP streams, envs being independent; --streams 1 = one launch per step).  Gaze actions are fixed-seed U(-1,1) and the planner result is a
 synthetic resident waypoint stream (the device follows it exactly as it follows a Primitive trajectory
 head; Oxford/Primitive themselves are host plugins in the reference and not part of this hot path —
 SURVEY.md 8(d) C2).  Inputs are resident in HBM before the timed region.  N>1: every rank steps its own
@@ -111,6 +112,9 @@ def main():
     ap.add_argument('--dist-backend', default='nccl', choices=['nccl', 'gloo'],
                     help='gloo + --single-device: dry run of the multi-rank path on a 1-GPU box')
     ap.add_argument('--single-device', action='store_true', help='every rank uses cuda:0 (dry run only)')
+    ap.add_argument('--streams', type=int, default=2,
+                    help='>1: the batch is cut into that many sub-batches stepped on free-running HIP streams (envs are '
+                         'independent); the roofline object then describes one sub-batch launch')
     ap.add_argument('--mode', default='launch', choices=['launch', 'graph'],
                     help='launch: one d2d_step launch per step; graph: the K launches captured in one hipGraph')
     args = ap.parse_args()
@@ -148,20 +152,33 @@ def main():
     wp = synth_plan(torch, T, B, params.map_size[0], params.map_size[1], 99 + rank, device)
     env.state.plan_ok.fill_(1)
     env.state.wp_valid.fill_(1)
-    st = env.state.struct()
-    cfg = env.cfg
     be = env.backend
     fn_step = be.fn['step']
     a_ptr, w_ptr = actions.data_ptr(), wp.data_ptr()
-    stream = torch.cuda.current_stream(device)
-    sp = C.c_void_p(stream.cuda_stream)
+    S = max(1, min(args.streams, B))
+    import copy
+    main_stream = torch.cuda.current_stream(device)
+    base = env.state.struct()
+    subs = []
+    for i in range(S):
+        lo, hi = (B * i) // S, (B * (i + 1)) // S
+        cfg_i = copy.copy(env.cfg)
+        cfg_i.B = hi - lo
+        st_i = A.State()
+        for name in A.STATE_FIELDS:
+            t = env.state.t.get(name)
+            ptr = getattr(base, name)
+            setattr(st_i, name, None if (t is None or not ptr) else ptr + lo * t.stride(0) * t.element_size())
+        stream_i = main_stream if S == 1 else torch.cuda.Stream(device)
+        subs.append((lo, cfg_i, st_i, stream_i, C.c_void_p(stream_i.cuda_stream)))
 
     def launch(t):
-        st.action = a_ptr + t * B * 8
-        st.wp = w_ptr + t * B * 6 * 8
-        rc = fn_step(C.byref(cfg), C.byref(st), sp)
-        if rc:
-            raise RuntimeError(be.fn['last_error']().decode())
+        for lo, cfg_i, st_i, _, sp_i in subs:
+            st_i.action = a_ptr + (t * B + lo) * 8
+            st_i.wp = w_ptr + (t * B + lo) * 6 * 8
+            rc = fn_step(C.byref(cfg_i), C.byref(st_i), sp_i)
+            if rc:
+                raise RuntimeError(be.fn['last_error']().decode())
 
     for t in range(Wm):
         launch(t)
@@ -169,10 +186,11 @@ def main():
 
     graph = None
     if args.mode == 'graph':
+        assert S == 1, '--mode graph needs --streams 1'
         graph = torch.cuda.CUDAGraph()
         cs = torch.cuda.Stream(device)
         with torch.cuda.graph(graph, stream=cs):
-            sp = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+            subs[0] = subs[0][:4] + (C.c_void_p(torch.cuda.current_stream(device).cuda_stream),)
             for t in range(Wm, T):
                 launch(t)
         torch.cuda.synchronize()
@@ -180,20 +198,22 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in subs]
     t0 = time.perf_counter()
-    e0.record(stream)
+    for (e0, _), sub in zip(ev, subs):
+        e0.record(sub[3])
     if graph is not None:
         graph.replay()
     else:
         for t in range(Wm, T):
             launch(t)
-    e1.record(stream)
+    for (_, e1), sub in zip(ev, subs):
+        e1.record(sub[3])
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    gpu_ms = e0.elapsed_time(e1)
+    gpu_ms = sum(e0.elapsed_time(e1) for e0, e1 in ev) / len(ev)      # HIP-event time of the K launches of a stream
 
     # episode statistics: the only exchange of the path (RCCL all_gather over xGMI), once per run
     stats = env.episode_stats()
@@ -209,7 +229,7 @@ def main():
     if rank == 0:
         value = world * B * K / elapsed
         launch_us = gpu_ms * 1e3 / K                       # HIP-event time per launch on the launch stream
-        achieved = ALGO_BYTES_PER_ENV_STEP * B / (launch_us * 1e-6) / 1e9
+        achieved = ALGO_BYTES_PER_ENV_STEP * (B / S) / (launch_us * 1e-6) / 1e9   # bytes of ONE launch / its duration
         traffic = None
         pj = os.path.join(ROOT, 'profiles', 'pmc_latest.json')
         if os.path.isfile(pj):
@@ -223,14 +243,16 @@ def main():
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': f'configs[1]: {B} batched envs per GPU x {args.agents} agents, agent_radius=15, '
                                    '50x50 uint8 grid, 50 rays, map_id=1+env',
-                       'envs_per_gpu': B, 'agents': env.N, 'launch_mode': args.mode,
+                       'envs_per_gpu': B, 'agents': env.N, 'launch_mode': args.mode, 'streams': S,
                        'gaze': 'fixed-seed U(-1,1) actions resident in HBM (Oxford is a host plugin)',
                        'planner': 'synthetic resident waypoint heads, followed as Primitive heads are '
                                   '(Primitive is a host plugin)',
                        'kalman_trackers': 'on device', 'auto_reset': False},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'kernel': 'k_stages (fused step)',
-                         'launch_us': launch_us, 'algo_bytes_per_env_step': ALGO_BYTES_PER_ENV_STEP},
+                         'launch_us': launch_us, 'envs_per_launch': B // S, 'concurrent_launches': S,
+                         'algo_bytes_per_env_step': ALGO_BYTES_PER_ENV_STEP,
+                         'aggregate_GBs': ALGO_BYTES_PER_ENV_STEP * B * K / elapsed / 1e9},
             'episode_stats': {'envs': int(stats.shape[0]), 'dynamic_collisions': int(stats[:, 3].sum()),
                               'mean_cells_discovered': float(stats[:, 6].double().mean())},
         }
