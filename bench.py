@@ -115,8 +115,10 @@ def main():
     ap.add_argument('--streams', type=int, default=2,
                     help='>1: the batch is cut into that many sub-batches stepped on free-running HIP streams (envs are '
                          'independent); the roofline object then describes one sub-batch launch')
-    ap.add_argument('--mode', default='launch', choices=['launch', 'graph'],
-                    help='launch: one d2d_step launch per step; graph: the K launches captured in one hipGraph')
+    ap.add_argument('--chunk', type=int, default=10, help='chain mode: steps queued per d2d_rollout call')
+    ap.add_argument('--mode', default='chain', choices=['chain', 'launch', 'graph'],
+                    help='chain: the K steps of a stream are queued by ONE d2d_rollout call (default); launch: one '
+                         'd2d_step call per step from Python; graph: the K launches captured in one hipGraph')
     args = ap.parse_args()
 
     import torch
@@ -171,6 +173,20 @@ def main():
             setattr(st_i, name, None if (t is None or not ptr) else ptr + lo * t.stride(0) * t.element_size())
         stream_i = main_stream if S == 1 else torch.cuda.Stream(device)
         subs.append((lo, cfg_i, st_i, stream_i, C.c_void_p(stream_i.cuda_stream)))
+    # chain mode: each sub-batch owns contiguous [T][b] actions and [T][b][6] planner heads
+    chain_in = [(actions[:, lo:lo + c_.B].contiguous(), wp[:, lo:lo + c_.B].contiguous()) for lo, c_, _, _, _ in subs]
+    fn_roll = be.fn['rollout']
+
+    def chain(t0, n, chunk=10):
+        # the chains are fed round-robin in chunks of `chunk` steps so that the streams stay abreast of each other
+        for c0 in range(t0, t0 + n, chunk):
+            m = min(chunk, t0 + n - c0)
+            for (lo, cfg_i, st_i, _, sp_i), (a_i, w_i) in zip(subs, chain_in):
+                b = cfg_i.B
+                rc = fn_roll(C.byref(cfg_i), C.byref(st_i), m, a_i.data_ptr() + c0 * b * 8,
+                             w_i.data_ptr() + c0 * b * 48, None, None, sp_i)
+                if rc:
+                    raise RuntimeError(be.fn['last_error']().decode())
 
     def launch(t):
         for lo, cfg_i, st_i, _, sp_i in subs:
@@ -180,8 +196,11 @@ def main():
             if rc:
                 raise RuntimeError(be.fn['last_error']().decode())
 
-    for t in range(Wm):
-        launch(t)
+    if args.mode == 'chain':
+        chain(0, Wm)
+    else:
+        for t in range(Wm):
+            launch(t)
     torch.cuda.synchronize()
 
     graph = None
@@ -204,6 +223,8 @@ def main():
         e0.record(sub[3])
     if graph is not None:
         graph.replay()
+    elif args.mode == 'chain':
+        chain(Wm, K, args.chunk)
     else:
         for t in range(Wm, T):
             launch(t)

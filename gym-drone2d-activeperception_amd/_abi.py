@@ -2,7 +2,7 @@
 the header exactly; tests/test_abi.py cross-checks sizes and constants against the header text."""
 import ctypes as C
 
-D2D_ABI_VERSION = 3
+D2D_ABI_VERSION = 4
 
 UNEXPLORED, OCCUPIED, UNOCCUPIED, DYNAMIC = 0, 1, 2, 3
 SM_WAIT_FOR_GOAL, SM_GOAL_REACHED, SM_PLANNING, SM_EXECUTING = 0, 1, 2, 3
@@ -51,7 +51,7 @@ def bind(lib, prefix='d2d_'):
         'perceive': (C.c_int, [P(Cfg), P(State), C.c_void_p]),
         'act': (C.c_int, [P(Cfg), P(State), C.c_void_p]),
         'run_stages': (C.c_int, [P(Cfg), P(State), C.c_uint32, C.c_void_p]),
-        'rollout': (C.c_int, [P(Cfg), P(State), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+        'rollout': (C.c_int, [P(Cfg), P(State), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
         'reset': (C.c_int, [P(Cfg), P(State), P(State), C.c_void_p, C.c_void_p]),
         'tan_array': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     }

@@ -56,8 +56,9 @@ class HipBackend:
     def act(self, cfg, st):
         self._chk(self.fn['act'](C.byref(cfg), C.byref(st), self._stream()))
 
-    def rollout(self, cfg, st, nsteps, actions, pin=None, coll_out=None):
+    def rollout(self, cfg, st, nsteps, actions, pin=None, coll_out=None, wp_steps=None):
         self._chk(self.fn['rollout'](C.byref(cfg), C.byref(st), nsteps, actions.data_ptr(),
+                                     None if wp_steps is None else wp_steps.data_ptr(),
                                      None if pin is None else pin.data_ptr(),
                                      None if coll_out is None else coll_out.data_ptr(), self._stream()))
 

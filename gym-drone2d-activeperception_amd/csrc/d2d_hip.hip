@@ -1347,8 +1347,8 @@ int d2d_perceive(const d2d_cfg *c, const d2d_state *s, void *stream) {
 }
 int d2d_act(const d2d_cfg *c, const d2d_state *s, void *stream) { return launch_stages(c, s, D2D_ST_ACT, stream); }
 
-int d2d_rollout(const d2d_cfg *c, const d2d_state *s, int32_t nsteps, const double *actions, const double *pin,
-                uint8_t *coll_out, void *stream) {
+int d2d_rollout(const d2d_cfg *c, const d2d_state *s, int32_t nsteps, const double *actions, const double *wp_steps,
+                const double *pin, uint8_t *coll_out, void *stream) {
   // nsteps fused steps queued back to back on the stream (one d2d_step-sized launch each, ~40 us of GPU work
   // against ~5 us of launch cost, so a device-side step loop buys nothing and costs registers)
   int rc = check(c, s);
@@ -1357,6 +1357,7 @@ int d2d_rollout(const d2d_cfg *c, const d2d_state *s, int32_t nsteps, const doub
   d2d_state st = *s;
   for (int32_t t = 0; t < nsteps; ++t) {
     st.action = actions + (size_t)t * c->B;
+    if (wp_steps) st.wp = wp_steps + (size_t)t * c->B * 6;
     rc = launch_stages(c, &st, D2D_ST_ALL, stream, pin, coll_out ? coll_out + (size_t)t * c->B : nullptr);
     if (rc) return rc;
   }

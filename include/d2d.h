@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define D2D_ABI_VERSION 3
+#define D2D_ABI_VERSION 4
 
 /* grid cell codes, utils.py:11-16 */
 #define D2D_UNEXPLORED 0
@@ -185,12 +185,13 @@ int d2d_act(const d2d_cfg *cfg, const d2d_state *st, void *stream);
 int d2d_run_stages(const d2d_cfg *cfg, const d2d_state *st, uint32_t stages, void *stream);
 
 /* `nsteps` consecutive fused steps queued back to back on the stream by ONE call (no host round trip
- * between them): the reference's inner loops that call step() back to back with host-independent actions
- * (glob_survivability_calculator.py:31-37).  actions: [nsteps][B]; optional pin: [B][2] drone
- * position forced before every step (env.drone.x = x; env.drone.y = y), or NULL;
- * coll_out: [nsteps][B] uint8 collision flag per step, or NULL. */
+ * between them): the reference's inner loops that call step() back to back with host-independent inputs
+ * (glob_survivability_calculator.py:31-37).  actions: [nsteps][B]; optional wp_steps: [nsteps][B][6]
+ * planner heads per step (EXTERNAL planner mode; st->plan_ok / st->wp_valid stay as given), or NULL to use
+ * st->wp every step; optional pin: [B][2] drone position forced before every step (env.drone.x = x;
+ * env.drone.y = y), or NULL; coll_out: [nsteps][B] uint8 collision flag per step, or NULL. */
 int d2d_rollout(const d2d_cfg *cfg, const d2d_state *st, int32_t nsteps, const double *actions,
-                const double *pin, uint8_t *coll_out, void *stream);
+                const double *wp_steps, const double *pin, uint8_t *coll_out, void *stream);
 
 /* reset(): for every env with mask[e] != 0 copy the snapshot `init` (same layouts, same B) over the
  * live state and clear outputs (envs/drone_v2.py:259-261 re-runs __init__; the host ran it once and

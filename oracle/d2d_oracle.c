@@ -489,7 +489,7 @@ int d2d_oracle_act(const d2d_cfg *c, const d2d_state *s, void *stream) {
 }
 
 int d2d_oracle_rollout(const d2d_cfg *c, const d2d_state *s, int32_t nsteps, const double *actions,
-                       const double *pin, uint8_t *coll_out, void *stream) {
+                       const double *wp_steps, const double *pin, uint8_t *coll_out, void *stream) {
   (void)stream;
   int rc = check(c, s);
   if (rc) return rc;
@@ -497,6 +497,7 @@ int d2d_oracle_rollout(const d2d_cfg *c, const d2d_state *s, int32_t nsteps, con
   d2d_state t = *s;
   for (int k = 0; k < nsteps; ++k) {
     t.action = actions + (size_t)k * c->B;
+    if (wp_steps) t.wp = wp_steps + (size_t)k * c->B * 6;
     if (pin)
       for (int e = 0; e < c->B; ++e) {
         s->drone[(size_t)e * D2D_DF + D2D_D_X] = pin[2 * e];
