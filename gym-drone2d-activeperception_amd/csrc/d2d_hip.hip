@@ -9,12 +9,15 @@
 //                                      ground-truth window the rays can reach is an LDS tile
 //   collision                        : lane = probe / agent, __any / __ballot reduction
 //   observation                      : an LDS tile of the drone's map that the rays patch in place
-// Memory schedule of one env-step (what the kernel is bound by is the chain of dependent HBM round
-// trips, ~2.5k cycles each, so there are exactly two plus the final stores):
-//   batch 1  everything whose address does not depend on data: pose, counters, inputs, agents, trackers
-//   batch 2  everything addressed by batch-1 data: ground-truth window and map crop (LDS-DMA, no VGPRs),
-//            dynamic-grid cells, collision probes -- issued together, tan / candidate work runs meanwhile
-//   stores   agents, drone map, grid, trackers, flags, observation: fire and forget
+// Memory schedule of one env-step -- two batches of loads, then fire-and-forget stores, no fence:
+//   batch 1  everything whose address does not depend on data: pose, counters, inputs, agents, tracker flags;
+//            the tracker states go to LDS by LDS-DMA (global_load_lds_dwordx4, no VGPRs)
+//   batch 2  everything addressed by batch-1 data: ground-truth window tile and drone-map crop tile (byte loads,
+//            all in flight before the first LDS write), dynamic-grid cells, collision probes -- issued together,
+//            the per-ray tan / candidate work runs meanwhile
+//   stores   agents, drone map, grid, trackers, flags, observation
+// What bounds the kernel is instruction issue (~2000 VALU + ~1500 SALU wave-instructions per env-step, fp64
+// heavy) and SGPR pressure, not bytes: see DESIGN.md section 3 for the measurements behind each choice.
 // There is no dense contraction on this path, hence no MFMA.  Arithmetic is fp64 in the reference's
 // own operation order (compiled with -ffp-contract=off; the few fused multiply-adds are the ones the
 // reference's runtime performs: libm tan, OpenBLAS dgemv), which is what makes the integer outputs
