@@ -120,6 +120,32 @@ def test_rollout_and_reset_on_device(pkg, hip, oracle):
     _assert_same(dev, ref, 'step after reset')
 
 
+@pytest.mark.parametrize('label,B,kw', [
+    ('config3', 65536, dict(agent_number=50, agent_radius=10, agent_max_speed=40, map_id=0, static_map='maps/random_map_0.npy')),
+    ('config4_shard', 32768, dict(agent_number=10, agent_radius=15, agent_max_speed=20, map_id=1, static_map='maps/obstacle_map.npy')),
+])
+def test_baseline_config_sizes(pkg, hip, label, B, kw):
+    """BASELINE configs 3 (65536 envs x 172 agents) and 4 (one GPU's shard: 32768 envs x 24 agents) at full size:
+    identical worlds stay identical, walls never change, the explored map only grows and agrees with gt."""
+    from drone2d_amd import vec_env, host_init
+    p = pkg.Params(planner='NoMove', **kw)
+    w = host_init.init_world(pkg.with_defaults(p))
+    env = vec_env.VecDrone2DEnv(p, B, backend=hip, worlds=[w] * B)
+    gt0 = env.state.gt[0].clone()
+    prev = torch.zeros_like(env.state.dmap[0], dtype=torch.bool)
+    for t in range(4):
+        env.step(0.37 * (t - 1))
+        s = env.state
+        for name in ('agents', 'gt', 'dmap', 'drone', 'flags', 'hit', 'obs_local', 'kf'):
+            x = s.t[name]
+            assert bool((x == x[0:1]).all()), f'{label}: {name} diverged across identical envs at step {t + 1}'
+        assert torch.equal(s.gt[0] == 1, gt0 == 1)
+        ex = s.dmap[0] != 0
+        assert bool((prev <= ex).all()) and bool(((s.dmap[0] == 1) <= (s.gt[0] == 1)).all())
+        prev = ex
+    assert env.N == w['N'] and int(prev.sum()) > 0
+
+
 def test_full_size_properties(pkg, hip):
     """BASELINE config 2 size (4096 envs x 10 agents): size-independent properties on the device alone:
     (i) a batch of identical worlds stays identical, (ii) wall cells of gt never change, explored cells only
