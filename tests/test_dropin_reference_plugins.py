@@ -76,3 +76,29 @@ def test_reference_primitive_and_oxford_drive_this_env(pkg, oracle, ref_modules)
         assert t == 210 and info['state_machine'] == 1 and (e.drone.x, e.drone.y) == (42, 455)
     finally:
         planners.register_planner('Primitive', own)
+
+
+def test_reference_experiment_driver_runs_unchanged(pkg, oracle, ref_modules):
+    """experiment.py of the reference (its Experiment class, unmodified) on this env: gym.make is pointed at
+    Drone2DEnv2, as the one-line registration change of INTEGRATION.md does."""
+    import gym
+    from drone2d_amd import env as envmod
+    fx = load('lookahead_primitive_n30_map3')
+    p = params_from(fx, pkg)
+    gym.make = lambda env_id, params=None: envmod.Drone2DEnv2(params, backend=oracle)
+    saved_path = list(sys.path)
+    sys.path.insert(0, REF)
+    cwd = os.getcwd()
+    os.chdir(REF)
+    try:
+        sys.modules.pop('experiment', None)
+        import experiment                       # the reference's driver module
+        ex = experiment.Experiment(p, '/tmp/unused.csv')
+        ex.run()
+        info = ex.env.info
+        assert ex.env.steps == len(fx['t_action']) and info['collision_flag'] == fx['t_flags'][-1][0]
+        assert np.array_equal(ex.env.drone.map.grid_map, fx['t_dmap'][-1])
+    finally:
+        os.chdir(cwd)
+        sys.path[:] = saved_path
+        sys.modules.pop('experiment', None)
