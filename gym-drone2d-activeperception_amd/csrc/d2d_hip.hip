@@ -596,7 +596,8 @@ __device__ __forceinline__ void ray_march(const d2d_cfg &c, const Geom &g, const
   const bool mask_path = ncand <= 32;
   const unsigned char *gtw = (const unsigned char *)L.gtw;
   unsigned char *dmt = (unsigned char *)L.dmt;
-  double x = x0, y = y0;
+  // sample 0 (the drone's own position, the same for every ray) was decided once by the caller
+  double x = x0 + ry.xs, y = y0 + ry.ys;
   bool alive = active && (0.0 < x && x < c.W_px && 0.0 < y && y < c.H_px);
   const int klo = g.klo;
   // The first candidate of this ray's mask (almost always the only one) is tested from registers on every
@@ -663,9 +664,9 @@ __device__ __forceinline__ void ray_march(const d2d_cfg &c, const Geom &g, const
   // not unrolled (a 10x body overflows the instruction cache); samples 0..klo cannot be past `depth`
   const int k1 = min(klo + 1, g.smax);
 #pragma unroll 1
-  for (int k = 0; k < k1; ++k) sample(std::false_type{});
+  for (int k = 1; k < k1; ++k) sample(std::false_type{});
 #pragma unroll 1
-  for (int k = k1; k < g.smax; ++k) sample(std::true_type{});
+  for (int k = max(k1, 1); k < g.smax; ++k) sample(std::true_type{});
 #endif
 }
 
@@ -1085,6 +1086,7 @@ __device__ __forceinline__ void run_env(const d2d_cfg &c, const d2d_state &s, in
   D2D_STAMP(4);
   int newly = 0;
   if (do_ray) {
+    bool go = false;  // do the rays continue past sample 0?
     for (int i0 = 0; i0 < c.R; i0 += WAVE) {
       const int i = i0 + lane;
       const Ray ry = ray_setup(c, L, i, ncand, x0, y0, yaw0);
@@ -1092,10 +1094,34 @@ __device__ __forceinline__ void run_env(const d2d_cfg &c, const d2d_state &s, in
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         wave_sync_lds();
         D2D_STAMP(5);
+        // Sample 0 of every ray is the drone's own position (utils.py:641-642), so its outcome is shared: an
+        // agent covering it stops every ray before the map is touched (:658-664), else its cell is recorded.
+        go = (0.0 < x0 && x0 < c.W_px && 0.0 < y0 && y0 < c.H_px);
+        bool cover = false;
+        for (int q = lane; q < ncand; q += WAVE) {
+          const double dx = L.cx[q] - x0, dy = L.cy[q] - y0;
+          if (go && dx * dx + dy * dy <= L.cr2[q]) {
+            L.hit[L.cidx[q]] = 1;
+            cover = true;
+          }
+        }
+        go = go && !__any(cover);
+        if (go) {  // dist == 0 < depth^2: only a wall stops the rays here
+          const unsigned char w0 = ((const unsigned char *)L.gtw)[wt.byte_index(g.reach, g.reach)];
+          const unsigned char v0 = (w0 == D2D_OCCUPIED) ? (unsigned char)D2D_OCCUPIED : (unsigned char)D2D_UNOCCUPIED;
+          if (lane == 0) {
+#ifndef D2D_ABL_NOSTORE
+            dm[ocx * H + ocy] = v0;
+#endif
+            const unsigned int pr = (unsigned int)(ocx - ct.i0), pq = (unsigned int)(ocy - ct.j0);
+            if (do_obs && pr < (unsigned int)ct.rows && pq < (unsigned int)ct.cols) ((unsigned char *)L.dmt)[pr * ct.cols + pq] = v0;
+          }
+          go = (w0 != D2D_OCCUPIED);
+        }
       }
       const bool general = ncand > 32 || __any((ry.cmask & (ry.cmask - 1u)) != 0u);
-      if (general) ray_march<true>(c, g, L, ry, i < c.R, ncand, x0, y0, wt, ct, do_obs, dm);
-      else ray_march<false>(c, g, L, ry, i < c.R, ncand, x0, y0, wt, ct, do_obs, dm);
+      if (general) ray_march<true>(c, g, L, ry, go && i < c.R, ncand, x0, y0, wt, ct, do_obs, dm);
+      else ray_march<false>(c, g, L, ry, go && i < c.R, ncand, x0, y0, wt, ct, do_obs, dm);
     }
     wave_sync_lds();
     D2D_STAMP(6);
