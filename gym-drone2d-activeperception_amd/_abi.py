@@ -2,11 +2,14 @@
 the header exactly; tests/test_abi.py cross-checks sizes and constants against the header text."""
 import ctypes as C
 
-D2D_ABI_VERSION = 4
+D2D_ABI_VERSION = 5
 
 UNEXPLORED, OCCUPIED, UNOCCUPIED, DYNAMIC = 0, 1, 2, 3
 SM_WAIT_FOR_GOAL, SM_GOAL_REACHED, SM_PLANNING, SM_EXECUTING = 0, 1, 2, 3
 PLANNER_EXTERNAL, PLANNER_NOMOVE = 0, 1
+PLAN_NONE, PLAN_PRIMITIVE = 0, 1
+GAZE_NONE, GAZE_OXFORD = 0, 1
+NODE_F = 12
 
 AF = 6
 A_PX, A_PY, A_VX, A_VY, A_R, A_R2 = range(6)
@@ -41,6 +44,20 @@ class State(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in STATE_FIELDS]
 
 
+PLAN_INT_FIELDS = ('planner', 'gaze', 'nu', 'n_sample', 'n_ts', 'max_itr', 'traj_cap', 'node_cap', 'hash_cap', 'n_yaw',
+                   'pw_nleaf', 'pw_nprog', 'tobs_len', 'reserved')
+PLAN_F64_FIELDS = ('horizon', 'vmax', 'safe_dist', 'goal_tol', 'agent_radius', 'half_fov', 'yaw_rate_max')
+PLAN_TABLES = ('u_space', 'sample_t', 'traj_t', 'yaw_space', 'tobs_tab', 'pw_leaf', 'pw_prog', 'trk_radius0')
+PLAN_STATE = ('traj', 'traj_hdr', 'trk_radius', 'trk_prev', 'seen_step', 'nodes', 'hash', 'plan_stat')
+
+
+class Plan(C.Structure):
+    """include/d2d.h `d2d_plan`."""
+    _fields_ = [(n, C.c_int32) for n in PLAN_INT_FIELDS] + [(n, C.c_double) for n in PLAN_F64_FIELDS] + \
+               [('acos_key_lo', C.c_int64), ('acos_mask', C.c_uint64)] + \
+               [(n, C.c_void_p) for n in PLAN_TABLES + PLAN_STATE]
+
+
 def bind(lib, prefix='d2d_'):
     """Declare argtypes / restypes of every entry point of include/d2d.h on a loaded CDLL."""
     P = C.POINTER
@@ -54,6 +71,11 @@ def bind(lib, prefix='d2d_'):
         'rollout': (C.c_int, [P(Cfg), P(State), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
         'reset': (C.c_int, [P(Cfg), P(State), P(State), C.c_void_p, C.c_void_p]),
         'tan_array': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+        'gaze_stage': (C.c_int, [P(Cfg), P(State), P(Plan), C.c_void_p]),
+        'plan_stage': (C.c_int, [P(Cfg), P(State), P(Plan), C.c_void_p]),
+        'closed_loop': (C.c_int, [P(Cfg), P(State), P(Plan), C.c_int32, C.c_int32, P(State), C.c_void_p]),
+        'plan_reset': (C.c_int, [P(Cfg), P(Plan), C.c_void_p, C.c_int32, C.c_void_p]),
+        'sincos_array': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     }
     out = {}
     for name, (res, args) in sig.items():
@@ -65,4 +87,4 @@ def bind(lib, prefix='d2d_'):
 
 
 ENTRY_POINTS = ('abi_version', 'last_error', 'step', 'perceive', 'act', 'run_stages', 'rollout', 'reset',
-                'tan_array')
+                'tan_array', 'gaze_stage', 'plan_stage', 'closed_loop', 'plan_reset', 'sincos_array')

@@ -391,7 +391,7 @@ __device__ __forceinline__ void st_control(const d2d_cfg &c, const StepIn &in, E
     r.ty = -1.0;
   }
   if (!in.ok) {
-    const double n = sqrt(r.vx * r.vx + r.vy * r.vy);
+    const double n = sqrt(__builtin_fma(r.vy, r.vy, r.vx * r.vx));  // numpy norm: sqrt(ddot) = sqrt(fma(y, y, x * x))
     if (n <= c.max_acc * c.dt) {
       r.vx = 0.0;
       r.vy = 0.0;
@@ -441,9 +441,10 @@ __device__ __forceinline__ void st_agents(const d2d_cfg &c, const d2d_state &s, 
       const double nx = px + velx * c.dt, ny = py + vely * c.dt;
       bool aliased = true;
       double pvx = velx, pvy = vely;
-      // norm(v) <= 5 (utils.py:476).  sqrt is correctly rounded and monotonic, and sqrt(s) rounds to <= 5 exactly
-      // for s <= nextafter(25) = 0x1.9000000000001p+4 (checked on the host), so the fp64 sqrt is not needed.
-      if (velx * velx + vely * vely <= 0x1.9000000000001p+4) {
+      // norm(v) <= 5 (utils.py:476), numpy's norm = sqrt(fma(vy, vy, vx * vx)) (OpenBLAS ddot).  sqrt is correctly
+      // rounded and monotonic, and sqrt(s) rounds to <= 5 exactly for s <= nextafter(25) = 0x1.9000000000001p+4
+      // (checked on the host), so the fp64 sqrt is not needed.
+      if (__builtin_fma(vely, vely, velx * velx) <= 0x1.9000000000001p+4) {
         // numpy 2x2 @ 2x1 (OpenBLAS dgemv): fma(M[r][0], v0, M[r][1] * v1); see oracle/d2d_oracle.c
         const double rx = __builtin_fma(cs, velx, (-sn) * vely);
         const double ry = __builtin_fma(sn, velx, cs * vely);
@@ -944,7 +945,7 @@ __device__ __forceinline__ void st_collide(const d2d_cfg &c, const d2d_state &s,
       // norm(d) < r + R (utils.py:774): decided by d.d against (r + R)^2 unless they agree to 1e-14, where the
       // correctly rounded sqrt of the reference decides
       const double dx = L.ax[k] - r.x, dy = L.ay[k] - r.y, t = L.ar[k] + R;
-      const double d2 = dx * dx + dy * dy, t2 = t * t;
+      const double d2 = __builtin_fma(dy, dy, dx * dx), t2 = t * t;  // numpy norm's dot product
       bool hit = d2 < t2 && t > 0.0;
       if (fabs(d2 - t2) <= 1e-14 * t2) hit = sqrt(d2) < t;
       dyn = dyn || hit;
@@ -954,8 +955,8 @@ __device__ __forceinline__ void st_collide(const d2d_cfg &c, const d2d_state &s,
   int dead = 0, frz = 0;
   if (col == 0) {
     const double gx = r.x - r.tx, gy = r.y - r.ty;
-    if (sqrt(gx * gx + gy * gy) <= 10.0) r.sm = D2D_SM_GOAL_REACHED;
-    const double vn = sqrt(r.vx * r.vx + r.vy * r.vy);
+    if (sqrt(__builtin_fma(gy, gy, gx * gx)) <= 10.0) r.sm = D2D_SM_GOAL_REACHED;
+    const double vn = sqrt(__builtin_fma(r.vy, r.vy, r.vx * r.vx));
     dead = (r.fail >= 10 && vn == 0.0) ? 1 : 0;
     frz = ((double)r.steps >= c.max_steps && !dead) ? 1 : 0;
   }
@@ -1236,11 +1237,11 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK, D2D_MIN_WAVES) void k_stages
 
 // reset(): masked copy of the snapshot over the live state, one wave per env
 __global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK) void k_reset(d2d_cfg c, d2d_state s, d2d_state init,
-                                                                 const unsigned char *mask) {
+                                                                 const unsigned char *mask, int mask_stride) {
   const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
   const int e = blockIdx.x * WAVES_PER_BLOCK + wv;
   if (e >= c.B) return;
-  if (mask && !mask[e]) return;
+  if (mask && !mask[(size_t)e * mask_stride]) return;
   const size_t N = c.N, WH = (size_t)c.W * c.H, LL = (size_t)c.L * c.L;
   for (size_t i = lane; i < D2D_AF * N; i += WAVE) s.agents[e * D2D_AF * N + i] = init.agents[e * D2D_AF * N + i];
   for (size_t i = lane; i < N; i += WAVE) {
@@ -1281,6 +1282,8 @@ __global__ void k_tan(const double *in, double *out, long long n) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = d2d_tan(in[i]);
 }
+
+#include "d2d_plugins.h"
 
 // ------------------------------------------------------------------------------------------------
 // host side of the C ABI
@@ -1354,6 +1357,80 @@ int launch_stages(const d2d_cfg *c, const d2d_state *s, uint32_t stages, void *s
   return 0;
 }
 
+int reset_launch(const d2d_cfg *c, const d2d_state *s, const d2d_state *init, const uint8_t *mask, int mask_stride,
+                 void *stream) {
+  int rc = check(c, s);
+  if (rc) return rc;
+  if (!init || !init->agents || !init->agent_unit || !init->dyn_prev || !init->gt || !init->dmap || !init->drone ||
+      !init->target || !init->targets || !init->counters || !init->active)
+    return fail(-1, "reset: incomplete snapshot");
+  if (c->B == 0) return 0;
+  const dim3 grid((c->B + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK), block(WAVE * WAVES_PER_BLOCK);
+  hipLaunchKernelGGL(k_reset, grid, block, 0, (hipStream_t)stream, *c, *s, *init, mask, mask_stride);
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) return fail(-3, hipGetErrorString(err));
+  return 0;
+}
+
+int plan_check(const d2d_cfg *c, const d2d_state *s, const d2d_plan *p) {
+  int rc = check(c, s);
+  if (rc) return rc;
+  if (!p) return fail(-1, "null plan");
+  if (p->planner == D2D_PLAN_PRIMITIVE || p->gaze == D2D_GAZE_OXFORD) {
+    if (!p->traj || !p->traj_hdr) return fail(-1, "plan: null trajectory buffers");
+    if (!c->kf_enabled) return fail(-4, "device plugins need the Kalman trackers on the device (kf_enabled)");
+  }
+  if (p->planner == D2D_PLAN_PRIMITIVE) {
+    if (!p->u_space || !p->sample_t || !p->traj_t || !p->trk_radius || !p->trk_prev || !p->nodes || !p->hash || !p->plan_stat)
+      return fail(-1, "plan: null planner pointer");
+    if (p->hash_cap <= p->node_cap || (p->hash_cap & (p->hash_cap - 1)))
+      return fail(-1, "plan: hash_cap must be a power of two > node_cap");
+    if (p->nu <= 0 || p->n_sample <= 0 || p->n_ts <= 0 || p->traj_cap < p->n_ts || p->node_cap < 2)
+      return fail(-1, "plan: bad planner dimensions");
+    if (!s->plan_ok || !s->wp_valid || !s->wp) return fail(-1, "plan: plan_ok / wp_valid / wp buffers missing");
+    if ((size_t)plan_wave_bytes(c->N) * WAVES_PER_BLOCK > 64 * 1024) return fail(-4, "plan: too many agents for the tracker staging in LDS");
+  }
+  if (p->gaze == D2D_GAZE_OXFORD) {
+    if (!p->yaw_space || !p->tobs_tab || !p->pw_leaf || !p->pw_prog || !p->seen_step) return fail(-1, "plan: null gaze pointer");
+    if (!s->action) return fail(-1, "plan: null action buffer");
+    if (p->n_yaw <= 0 || p->n_yaw > 8) return fail(-4, "gaze: at most 8 yaw-rate candidates");
+    if (p->pw_nleaf <= 0 || p->pw_nprog != 2 * p->pw_nleaf - 1) return fail(-1, "gaze: bad pairwise-sum program");
+    if ((size_t)gaze_geom(*c, *p).wave_bytes * WAVES_PER_BLOCK > 64 * 1024)
+      return fail(-4, "gaze: map / view depth too large for the per-env LDS working set");
+    if (c->max_steps + 2 > (double)p->tobs_len) return fail(-1, "gaze: tobs_tab shorter than the longest episode");
+  }
+  return 0;
+}
+
+int gaze_launch(const d2d_cfg *c, const d2d_state *s, const d2d_plan *p, void *stream) {
+  if (p->gaze != D2D_GAZE_OXFORD || c->B == 0) return 0;
+  const dim3 grid((c->B + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK), block(WAVE * WAVES_PER_BLOCK);
+  const size_t lds = (size_t)gaze_geom(*c, *p).wave_bytes * WAVES_PER_BLOCK;
+  hipLaunchKernelGGL(k_gaze, grid, block, lds, (hipStream_t)stream, *c, *s, *p);
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) return fail(-3, hipGetErrorString(err));
+  return 0;
+}
+
+int plan_launch(const d2d_cfg *c, const d2d_state *s, const d2d_plan *p, void *stream) {
+  if (p->planner != D2D_PLAN_PRIMITIVE || c->B == 0) return 0;
+  const dim3 grid((c->B + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK), block(WAVE * WAVES_PER_BLOCK);
+  const size_t lds = (size_t)plan_wave_bytes(c->N) * WAVES_PER_BLOCK;
+  hipLaunchKernelGGL(k_plan, grid, block, lds, (hipStream_t)stream, *c, *s, *p);
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) return fail(-3, hipGetErrorString(err));
+  return 0;
+}
+
+int plan_reset_launch(const d2d_cfg *c, const d2d_plan *p, const uint8_t *mask, int mask_stride, void *stream) {
+  if (c->B == 0) return 0;
+  const dim3 grid((c->B + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK), block(WAVE * WAVES_PER_BLOCK);
+  hipLaunchKernelGGL(k_plan_reset, grid, block, 0, (hipStream_t)stream, *c, *p, mask, mask_stride);
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) return fail(-3, hipGetErrorString(err));
+  return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1394,14 +1471,59 @@ int d2d_rollout(const d2d_cfg *c, const d2d_state *s, int32_t nsteps, const doub
 }
 
 int d2d_reset(const d2d_cfg *c, const d2d_state *s, const d2d_state *init, const uint8_t *mask, void *stream) {
-  int rc = check(c, s);
+  return reset_launch(c, s, init, mask, 1, stream);
+}
+
+int d2d_gaze_stage(const d2d_cfg *c, const d2d_state *s, const d2d_plan *p, void *stream) {
+  int rc = plan_check(c, s, p);
   if (rc) return rc;
-  if (!init || !init->agents || !init->agent_unit || !init->dyn_prev || !init->gt || !init->dmap || !init->drone ||
-      !init->target || !init->targets || !init->counters || !init->active)
-    return fail(-1, "reset: incomplete snapshot");
-  if (c->B == 0) return 0;
-  const dim3 grid((c->B + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK), block(WAVE * WAVES_PER_BLOCK);
-  hipLaunchKernelGGL(k_reset, grid, block, 0, (hipStream_t)stream, *c, *s, *init, mask);
+  return gaze_launch(c, s, p, stream);
+}
+
+int d2d_plan_stage(const d2d_cfg *c, const d2d_state *s, const d2d_plan *p, void *stream) {
+  int rc = plan_check(c, s, p);
+  if (rc) return rc;
+  return plan_launch(c, s, p, stream);
+}
+
+int d2d_plan_reset(const d2d_cfg *c, const d2d_plan *p, const uint8_t *mask, int32_t mask_stride, void *stream) {
+  if (!c || !p) return fail(-1, "null cfg/plan");
+  if (c->abi_version != D2D_ABI_VERSION) return fail(-2, "ABI version mismatch");
+  return plan_reset_launch(c, p, mask, mask_stride, stream);
+}
+
+int d2d_closed_loop(const d2d_cfg *c, const d2d_state *s, const d2d_plan *p, int32_t nsteps, int32_t auto_reset,
+                    const d2d_state *init, void *stream) {
+  // gaze -> perceive -> plan -> act per step, all queued on the stream (experiment.py:68-70)
+  int rc = plan_check(c, s, p);
+  if (rc) return rc;
+  if (nsteps < 0) return fail(-1, "closed_loop: bad step count");
+  if (auto_reset && !init) return fail(-1, "closed_loop: auto_reset needs the snapshot");
+  const bool split = p->planner == D2D_PLAN_PRIMITIVE;
+  for (int32_t t = 0; t < nsteps; ++t) {
+    if ((rc = gaze_launch(c, s, p, stream))) return rc;
+    if (split) {
+      if ((rc = launch_stages(c, s, D2D_ST_PERCEIVE, stream))) return rc;
+      if ((rc = plan_launch(c, s, p, stream))) return rc;
+      if ((rc = launch_stages(c, s, D2D_ST_ACT, stream))) return rc;
+    } else if ((rc = launch_stages(c, s, D2D_ST_ALL, stream))) {
+      return rc;
+    }
+    if (auto_reset) {  // the next episode starts from the seeded world with fresh plugin objects (main.py:26-57)
+      // plugin state first: the state reset clears the flags both use as their mask
+      if ((rc = plan_reset_launch(c, p, s->flags + D2D_F_DONE, 4, stream))) return rc;
+      if ((rc = reset_launch(c, s, init, s->flags + D2D_F_DONE, 4, stream))) return rc;
+    }
+  }
+  return 0;
+}
+
+int d2d_sincos_array(const double *in, double *so, double *co, int64_t n, void *stream) {
+  if (n < 0 || (n > 0 && (!in || !so || !co))) return fail(-1, "sincos_array: bad arguments");
+  if (n == 0) return 0;
+  const int bs = 256;
+  hipLaunchKernelGGL(k_sincos, dim3((unsigned)((n + bs - 1) / bs)), dim3(bs), 0, (hipStream_t)stream, in, so, co,
+                     (long long)n);
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return fail(-3, hipGetErrorString(err));
   return 0;

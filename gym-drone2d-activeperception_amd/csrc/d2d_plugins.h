@@ -1,0 +1,661 @@
+// d2d_plugins.h — the reference's planner / gaze plugins as device stages (include/d2d.h d2d_plan; SURVEY
+// section 8 rows f2, f3).  Included by d2d_hip.hip inside its anonymous namespace.
+//
+//   k_plan   Primitive.replan_check + Primitive.plan (traj_planner.py:125-233) + the head waypoint step_pos consumes
+//   k_gaze   Oxford.plan (yaw_planner.py:81-127)
+//
+// Mapping: ONE WAVEFRONT PER ENV, like the fused step: envs never talk to each other, every hand-off is lane ->
+// lane inside one wave (LDS, or the env's own global scratch behind wave_sync_global()).
+//   search            lane = motion primitive (8 x 8 accelerations = one wave); the open set is an append-only node
+//                     array in the env's scratch (Python dict order = insertion order = slot order), min() is a
+//                     strided scan + lexicographic wave reduction, the dict lookup an open-addressing hash table;
+//                     the successors of one expansion are de-duplicated among the lanes with ballot / readlane and
+//                     inserted together, which gives the same final dict as the reference's one-by-one loop
+//   replan_check      lane = trajectory waypoint, __any over the wave
+//   view maps         lane = cell of the 2 * depth bounding box around the viewpoint (cells outside cannot be seen)
+//   np.sum            numpy's pairwise order: lane = (candidate, accumulator 0..7) walks one <= 128-element block,
+//                     ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) by three shuffles, blocks added by the host's program
+// Arithmetic is fp64 in the reference's operation order with numpy's measured roundings (oracle/d2d_oracle.c lists
+// them); sin / cos are csrc/d2d_sincos.h, arccos(q) <= half_fov is the host's decision window.
+
+#define D2D_SINCOS_QUAL __device__ __forceinline__
+#define D2D_SINCOS_TBL_QUAL __device__ const
+#include "d2d_sincos.h"
+
+__device__ __forceinline__ double norm2(double x, double y) { return sqrt(__builtin_fma(y, y, x * x)); }
+
+__device__ __forceinline__ double shfl_f64(double v, int src) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __shfl(lo, src, WAVE);
+  hi = __shfl(hi, src, WAVE);
+  return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ long long shfl_i64(long long v, int src) {
+  int lo = (int)(v & 0xffffffffll), hi = (int)(v >> 32);
+  lo = __shfl(lo, src, WAVE);
+  hi = __shfl(hi, src, WAVE);
+  return ((long long)hi << 32) | (unsigned int)lo;
+}
+
+// drone.map.get_grid (utils.py:545-548) on the explored map; NaN coordinates are refused before this is called
+__device__ __forceinline__ bool dm_is_wall(const d2d_cfg &c, const unsigned char *__restrict__ dm, double x, double y,
+                                           double inv_scale) {
+  const bool oob = (x >= c.W_px || x < 0.0 || y >= c.H_px || y < 0.0);
+  const int ci = min(max(cell_fast(x, c.scale, inv_scale), 0), c.W - 1), cj = min(max(cell_fast(y, c.scale, inv_scale), 0), c.H - 1);
+  return oob || dm[ci * c.H + cj] == D2D_OCCUPIED;
+}
+
+struct TrkView {  // active trackers of the env, compacted into LDS
+  double *mx, *my, *vx, *vy, *lim_plan, *lim_replan;
+  int n;
+};
+
+// Planner.is_free, traj_planner.py:28-59
+__device__ __forceinline__ bool plan_is_free(const d2d_cfg &c, const d2d_plan &p, const unsigned char *__restrict__ dm,
+                                             const TrkView &T, double x, double y, double t, double inv_scale) {
+  if (x != x || y != y) return false;
+  const double d = p.safe_dist;
+  bool wall = dm_is_wall(c, dm, x - d, y, inv_scale);
+  wall = wall | dm_is_wall(c, dm, x, y, inv_scale);
+  wall = wall | dm_is_wall(c, dm, x + d, y, inv_scale);
+  wall = wall | dm_is_wall(c, dm, x, y - d, inv_scale);
+  wall = wall | dm_is_wall(c, dm, x, y + d, inv_scale);
+  bool hit = false;
+  for (int q = 0; q < T.n; ++q) {
+    const double ex = T.mx[q] + t * T.vx[q], ey = T.my[q] + t * T.vy[q];  // estimate_pos, utils.py:220-223
+    hit = hit | (norm2(x - ex, y - ey) <= T.lim_plan[q]);
+  }
+  return !wall && !hit;
+}
+
+__device__ __forceinline__ long long py_ifloordiv10(long long a) {
+  long long d = a / 10;
+  if ((a % 10 != 0) && (a < 0)) --d;
+  return d;
+}
+
+// Primitive_Node.get_index, traj_planner.py:93
+__device__ __forceinline__ long long node_key(double px, double py, double vx, double vy) {
+  const long long a = py_ifloordiv10((long long)rint(px)), b = py_ifloordiv10((long long)rint(py));
+  const long long cc = (long long)rint(vx), d = (long long)rint(vy);
+  return (long long)((((unsigned long long)(a + 32768) & 0xffffull) << 48) | (((unsigned long long)(b + 32768) & 0xffffull) << 32) |
+                     (((unsigned long long)(cc + 32768) & 0xffffull) << 16) | ((unsigned long long)(d + 32768) & 0xffffull));
+}
+
+__device__ __forceinline__ unsigned int key_hash(long long k) {
+  return (unsigned int)(((unsigned long long)k * 0x9E3779B97F4A7C15ull) >> 32);
+}
+
+// Scratch layout of one env's search (private to this file): planes of node_cap entries each.
+struct NodePlanes {
+  double *px, *py, *vx, *vy, *cost, *total, *ax, *ay;
+  int2 *link;        // parent slot, itr
+  long long *key;
+  long long *state;  // 1 open, 2 closed
+};
+
+__device__ __forceinline__ NodePlanes node_planes(double *base, int cap) {
+  NodePlanes n;
+  n.px = base;
+  n.py = n.px + cap;
+  n.vx = n.py + cap;
+  n.vy = n.vx + cap;
+  n.cost = n.vy + cap;
+  n.total = n.cost + cap;
+  n.ax = n.total + cap;
+  n.ay = n.ax + cap;
+  n.link = (int2 *)(n.ay + cap);
+  n.key = (long long *)(n.ay + 2 * (size_t)cap);
+  n.state = n.key + cap;
+  return n;
+}
+
+// Primitive.plan's search (traj_planner.py:128-218) by one wave.  Returns the number of waypoints written (0 = failure).
+__device__ int plan_search(const d2d_cfg &c, const d2d_state &s, const d2d_plan &p, int e, int lane, const TrkView &T,
+                           int *chain, const unsigned char *__restrict__ dm, double inv_scale) {
+  const double H = p.horizon;
+  const NodePlanes nd = node_planes(p.nodes + (size_t)e * p.node_cap * D2D_NODE_F, p.node_cap);
+  int *__restrict__ tab = p.hash + (size_t)e * p.hash_cap;
+  double *__restrict__ traj = p.traj + (size_t)e * p.traj_cap * 4;
+  int *stat = p.plan_stat + (size_t)e * 4;
+  const unsigned int hmask = (unsigned int)p.hash_cap - 1u;
+  const double tx = s.target[(size_t)e * 2], ty = s.target[(size_t)e * 2 + 1];
+  const double *dr = s.drone + (size_t)e * D2D_DF;
+
+  for (int i = lane; i < p.hash_cap; i += WAVE) tab[i] = 0;
+  wave_sync_global();
+  if (lane == 0) {
+    const double x = dr[D2D_D_X], y = dr[D2D_D_Y], vx = dr[D2D_D_VX], vy = dr[D2D_D_VY];
+    nd.px[0] = x; nd.py[0] = y; nd.vx[0] = vx; nd.vy[0] = vy;
+    nd.cost[0] = 0.0;
+    nd.total[0] = 0.0 + 0.5 * norm2(x - tx, y - ty) + 0.1 * norm2(vx, vy);  // traj_planner.py:88
+    nd.ax[0] = 0.0; nd.ay[0] = 0.0;
+    nd.link[0] = make_int2(-1, 0);
+    const long long k = node_key(x, y, vx, vy);
+    nd.key[0] = k;
+    nd.state[0] = 1;
+    tab[key_hash(k) & hmask] = 1;
+  }
+  wave_sync_global();
+  int nn = 1, open_n = 1, goal = -1, itr = 0, expansions = 0;
+  bool overflow = false;
+  const int nprim = p.nu * p.nu;
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  for (;;) {
+    itr += 1;
+    if (open_n == 0 || itr >= p.max_itr) break;
+    // ---- min(open_set, key=total_cost): first minimal entry in insertion (= slot) order ----
+    double best = 0.0;
+    int bidx = 0x7fffffff;
+    for (int s0 = 0; s0 < nn; s0 += WAVE) {
+      const int si = s0 + lane;
+      if (si < nn && nd.state[si] == 1) {
+        const double t = nd.total[si];
+        if (bidx == 0x7fffffff || t < best) {
+          best = t;
+          bidx = si;
+        }
+      }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+      const double t2 = shfl_f64(best, lane ^ o);
+      const int i2 = __shfl(bidx, lane ^ o, WAVE);
+      const bool take = (i2 != 0x7fffffff) && (bidx == 0x7fffffff || t2 < best || (t2 == best && i2 < bidx));
+      if (take) {
+        best = t2;
+        bidx = i2;
+      }
+    }
+    const int cur = __builtin_amdgcn_readfirstlane(bidx);
+    const double px = nd.px[cur], py = nd.py[cur], vx = nd.vx[cur], vy = nd.vy[cur], ccost = nd.cost[cur];
+    const int citr = nd.link[cur].y;
+    if (norm2(px - tx, py - ty) <= p.goal_tol) {  // :158
+      goal = cur;
+      break;
+    }
+    if (lane == 0) nd.state[cur] = 2;
+    open_n -= 1;
+    expansions += 1;
+    // ---- expand: lane = primitive, batches of 64 in generation order (x_acc outer, y_acc inner) ----
+    for (int p0 = 0; p0 < nprim && !overflow; p0 += WAVE) {
+      const int pi = p0 + lane;
+      bool ok = pi < nprim;
+      const int ia = ok ? pi / p.nu : 0, ja = ok ? pi - ia * p.nu : 0;
+      const double ax = p.u_space[ia], ay = p.u_space[ja];
+      const double hx = ax / 2, hy = ay / 2;
+      const double vex = vx + (2 * H) * hx, vey = vy + (2 * H) * hy;  // :172,183
+      ok = ok && (norm2(vex, vey) < p.vmax);
+      for (int si = 0; si < p.n_sample; ++si) {  // :175-180
+        if (!__any(ok)) break;
+        const double t = p.sample_t[2 * si], t2 = p.sample_t[2 * si + 1];
+        const double sx = rint(__builtin_fma(t2, hx, px + t * vx)), sy = rint(__builtin_fma(t2, hy, py + t * vy));
+        const bool fr = plan_is_free(c, p, dm, T, sx, sy, t + (double)citr * H, inv_scale);
+        ok = ok && fr;
+      }
+      const double ex = rint((px + H * vx) + (H * H) * hx), ey = rint((py + H * vy) + (H * H) * hy);  // :182
+      const double cost = ccost + (ax * ax + ay * ay) / 100 + 10;                                     // :184
+      const long long key = node_key(ex, ey, vex, vey);
+      // ---- :192-202 for all successors of the batch at once ----
+      int slot = -1;
+      if (ok) {
+        unsigned int h = key_hash(key) & hmask;
+        for (int guard = 0; guard < p.hash_cap; ++guard) {
+          const int sv = __hip_atomic_load(&tab[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // written by atomics
+          if (sv == 0) break;
+          if (nd.key[sv - 1] == key) {
+            slot = sv - 1;
+            break;
+          }
+          h = (h + 1) & hmask;
+        }
+      }
+      const unsigned long long m = __ballot(ok);
+      int leader = lane, wlane = -1;
+      double wcost = 0.0;
+      for (unsigned long long mm = m; mm; mm &= mm - 1) {
+        const int b = __ffsll((long long)mm) - 1;
+        const long long kb = shfl_i64(key, b);
+        const double cb = shfl_f64(cost, b);
+        if (ok && kb == key) {
+          if (b < leader) leader = b;
+          if (wlane < 0 || cb < wcost) {
+            wcost = cb;
+            wlane = b;
+          }
+        }
+      }
+      const bool is_leader = ok && leader == lane;
+      const bool exists = slot >= 0;
+      bool closed = false;
+      double ecost = 0.0;
+      if (ok && exists) {
+        closed = nd.state[slot] == 2;
+        ecost = nd.cost[slot];
+      }
+      const unsigned long long newm = __ballot(is_leader && !exists);
+      const int nnew = __popcll(newm);
+      if (nn + nnew > p.node_cap) {
+        overflow = true;
+        break;
+      }
+      int myslot = slot;
+      if (is_leader && !exists) myslot = nn + __popcll(newm & lt_mask);
+      const int gslot = __shfl(myslot, leader, WAVE);  // the slot of my group
+      const bool write = ok && wlane == lane && (!exists || (!closed && ecost > wcost));
+      if (write) {
+        nd.px[gslot] = ex; nd.py[gslot] = ey; nd.vx[gslot] = vex; nd.vy[gslot] = vey;
+        nd.cost[gslot] = cost;
+        nd.total[gslot] = cost + 0.5 * norm2(ex - tx, ey - ty) + 0.1 * norm2(vex, vey);
+        nd.ax[gslot] = ax; nd.ay[gslot] = ay;
+        nd.link[gslot] = make_int2(cur, citr + 1);
+        nd.key[gslot] = key;
+        nd.state[gslot] = 1;
+      }
+      if (is_leader && !exists) {
+        unsigned int h = key_hash(key) & hmask;
+        for (int guard = 0; guard < p.hash_cap; ++guard) {
+          if (atomicCAS(&tab[h], 0, myslot + 1) == 0) break;
+          h = (h + 1) & hmask;
+        }
+      }
+      nn += nnew;
+      open_n += nnew;
+      wave_sync_global();
+    }
+    if (overflow) break;
+    wave_sync_global();
+  }
+  if (lane == 0) {
+    stat[0] += 1;
+    stat[1] = expansions;
+    stat[2] = nn;
+    if (overflow) stat[3] = 1;
+  }
+  if (goal < 0 || overflow) return 0;
+  // ---- :207-216: waypoints of every primitive on the path, start side first ----
+  int depth = 0;
+  for (int q = goal; q != 0; q = nd.link[q].x) depth += 1;
+  if (depth * p.n_ts > p.traj_cap || depth > 128) {
+    if (lane == 0) stat[3] = 1;
+    return 0;
+  }
+  if (lane == 0) {
+    int q = goal;
+    for (int lvl = depth - 1; lvl >= 0; --lvl) {
+      chain[lvl] = q;
+      q = nd.link[q].x;
+    }
+  }
+  wave_sync_lds();
+  const int total = depth * p.n_ts;
+  for (int w0 = 0; w0 < total; w0 += WAVE) {
+    const int w = w0 + lane;
+    if (w < total) {
+      const int lvl = w / p.n_ts, mi = w - lvl * p.n_ts;
+      const int q = chain[lvl], par = nd.link[q].x;
+      const double hx = nd.ax[q] / 2, hy = nd.ay[q] / 2;
+      const double t = p.traj_t[3 * mi], t2 = p.traj_t[3 * mi + 1], tt = p.traj_t[3 * mi + 2];
+      const double ppx = nd.px[par], ppy = nd.py[par], pvx = nd.vx[par], pvy = nd.vy[par];
+      double *o = traj + (size_t)w * 4;
+      o[0] = rint(__builtin_fma(t2, hx, ppx + t * pvx));  // :121
+      o[1] = rint(__builtin_fma(t2, hy, ppy + t * pvy));
+      o[2] = pvx + tt * hx;                               // :122
+      o[3] = pvy + tt * hy;
+    }
+  }
+  return total;
+}
+
+extern __shared__ __attribute__((aligned(16))) char d2d_plug_lds[];
+
+// LDS per wave of k_plan: 6 planes of ncap doubles (active trackers) + 128 ints (path)
+__host__ __device__ inline int plan_wave_bytes(int N) {
+  const int ncap = ((N > 0 ? N : 1) + 3) & ~3;
+  return 6 * 8 * ncap + 128 * 4;
+}
+
+__global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK) void k_plan(d2d_cfg c, d2d_state s, d2d_plan p) {
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);
+  const int e = blockIdx.x * WAVES_PER_BLOCK + wv;
+  if (e >= c.B) return;
+  const int N = c.N, ncap = ((N > 0 ? N : 1) + 3) & ~3;
+  char *base = d2d_plug_lds + (size_t)wv * plan_wave_bytes(N);
+  TrkView T;
+  T.mx = (double *)base;
+  T.my = T.mx + ncap;
+  T.vx = T.my + ncap;
+  T.vy = T.vx + ncap;
+  T.lim_plan = T.vy + ncap;
+  T.lim_replan = T.lim_plan + ncap;
+  int *chain = (int *)(T.lim_replan + ncap);
+  const double inv_scale = 1.0 / c.scale;
+  const unsigned char *__restrict__ dm = s.dmap + (size_t)e * c.W * c.H;
+  // ---- trackers: archive bookkeeping (utils.py:184,238) and the active ones into LDS ----
+  int nact = 0;
+  for (int k0 = 0; k0 < N; k0 += WAVE) {
+    const int k = k0 + lane;
+    bool act = false;
+    double m0 = 0, m1 = 0, m2 = 0, m3 = 0, rad = 0;
+    if (k < N) {
+      act = s.active[(size_t)e * N + k] != 0;
+      const bool prev = p.trk_prev[(size_t)e * N + k] != 0;
+      rad = p.trk_radius[(size_t)e * N + k];
+      if (prev && !act) {
+        rad = p.agent_radius;
+        p.trk_radius[(size_t)e * N + k] = rad;
+      }
+      if (prev != act) p.trk_prev[(size_t)e * N + k] = act ? 1 : 0;
+      if (act) {
+        const double *mu = s.kf + ((size_t)e * N + k) * D2D_KF;
+        m0 = mu[0]; m1 = mu[1]; m2 = mu[2]; m3 = mu[3];
+      }
+    }
+    const unsigned long long am = __ballot(act);
+    if (act) {
+      const int q = nact + __popcll(am & ((1ull << lane) - 1ull));
+      T.mx[q] = m0; T.my[q] = m1; T.vx[q] = m2; T.vy[q] = m3;
+      T.lim_plan[q] = c.drone_radius + rad + 5 + c.sigma;  // traj_planner.py:58
+      T.lim_replan[q] = c.drone_radius + rad;              // traj_planner.py:228
+    }
+    nact += __popcll(am);
+  }
+  T.n = nact;
+  wave_sync_lds();
+  // ---- replan_check, traj_planner.py:220-233 ----
+  int *hdr = p.traj_hdr + (size_t)e * 2;
+  int head = hdr[0], stored = hdr[1];
+  double *__restrict__ traj = p.traj + (size_t)e * p.traj_cap * 4;
+  {
+    const int n = stored - head;
+    bool bad = false;
+    for (int i0 = 0; i0 < n; i0 += WAVE) {
+      const int i = i0 + lane;
+      if (i < n) {
+        const double *w = traj + (size_t)(head + i) * 4;
+        const double wx = w[0], wy = w[1];
+        const double ti = (double)i * c.dt;
+        const int ci = cell_fast(wx, c.scale, inv_scale), cj = cell_fast(wy, c.scale, inv_scale);
+        const bool in = ci >= 0 && ci < c.W && cj >= 0 && cj < c.H;
+        // swep_map is uint8: the stored value is trunc(i * dt); a wall under a non-zero stored value forces the replan
+        const int sv = ((int)ti) & 0xff;
+        if (in && sv > 0 && dm[min(max(ci, 0), c.W - 1) * c.H + min(max(cj, 0), c.H - 1)] == D2D_OCCUPIED) bad = true;
+        for (int q = 0; q < nact; ++q) {
+          const double ex = T.mx[q] + ti * T.vx[q], ey = T.my[q] + ti * T.vy[q];
+          if (norm2(ex - wx, ey - wy) <= T.lim_replan[q]) bad = true;
+        }
+      }
+    }
+    if (__any(bad)) head = stored = 0;
+  }
+  // ---- plan, traj_planner.py:125-218 ----
+  int ok = 1;
+  if (stored - head == 0) {
+    head = 0;
+    stored = plan_search(c, s, p, e, lane, T, chain, dm, inv_scale);
+    ok = stored > 0 ? 1 : 0;
+    wave_sync_global();
+  }
+  // ---- the head step_pos will consume (utils.py:733-739) ----
+  if (lane == 0) {
+    unsigned char *plan_ok = (unsigned char *)s.plan_ok, *wp_valid = (unsigned char *)s.wp_valid;
+    double *wp = (double *)s.wp + (size_t)e * 6;
+    plan_ok[e] = (unsigned char)ok;
+    if (stored - head > 0) {
+      const double *w = traj + (size_t)head * 4;
+      wp[0] = w[0]; wp[1] = w[1]; wp[2] = w[2]; wp[3] = w[3]; wp[4] = 0.0; wp[5] = 0.0;
+      wp_valid[e] = 1;
+      head += 1;
+    } else {
+      wp_valid[e] = 0;
+      for (int i = 0; i < 6; ++i) wp[i] = 0.0;
+    }
+    hdr[0] = head;
+    hdr[1] = stored;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Oxford
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ long long dkey(double x) {
+  const long long b = __double_as_longlong(x);
+  return b ^ ((b >> 63) & 0x7FFFFFFFFFFFFFFFll);
+}
+
+// np.arccos(q) <= view_angle (yaw_planner.py:77) through the host's decision window
+__device__ __forceinline__ bool acos_le(const d2d_plan &p, double q) {
+  if (!(fabs(q) <= 1.0)) return false;
+  const long long k = dkey(q);
+  if (k >= p.acos_key_lo + 64) return true;
+  if (k < p.acos_key_lo) return false;
+  return ((p.acos_mask >> (int)(k - p.acos_key_lo)) & 1ull) != 0ull;
+}
+
+// Oxford.get_view_map (yaw_planner.py:67-79) for the cell whose origin is (x, y)
+__device__ __forceinline__ bool view_cell(const d2d_plan &p, double depth2, double x0, double y0, double cy, double sy,
+                                          double x, double y) {
+  const double a = x0 - x, b = y0 - y;
+  const double d2 = a * a + b * b;
+  if (d2 <= 0.0) return true;
+  const double q = ((x - x0) * cy + (y - y0) * sy) / sqrt(d2);
+  return acos_le(p, q) && d2 <= depth2;
+}
+
+struct GazeGeom {
+  int bbn;    // cells per axis of the bounding box of a view disk
+  int ncell;  // bbn * bbn
+  int wave_bytes;
+};
+
+__host__ __device__ inline GazeGeom gaze_geom(const d2d_cfg &c, const d2d_plan &p) {
+  GazeGeom g;
+  g.bbn = 2 * ((int)(c.depth / c.scale) + 1) + 3;
+  g.ncell = g.bbn * g.bbn;
+  // int swept index + double reward + candidate bits per box cell, block sums + add stacks per candidate
+  const int bytes = 4 * g.ncell + 8 * g.ncell + ((g.ncell + 7) & ~7) + 8 * p.n_yaw * p.pw_nleaf + 8 * p.n_yaw * 16;
+  g.wave_bytes = (bytes + 15) & ~15;
+  return g;
+}
+
+__global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK) void k_gaze(d2d_cfg c, d2d_state s, d2d_plan p) {
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);
+  const int e = blockIdx.x * WAVES_PER_BLOCK + wv;
+  if (e >= c.B) return;
+  const GazeGeom g = gaze_geom(c, p);
+  char *base = d2d_plug_lds + (size_t)wv * g.wave_bytes;
+  double *rew = (double *)base;                                   // [ncell]
+  double *lsum = rew + g.ncell;                                   // [n_yaw][pw_nleaf]
+  double *stk = lsum + p.n_yaw * p.pw_nleaf;                      // [n_yaw][16]
+  int *swi = (int *)(stk + p.n_yaw * 16);                         // [ncell]
+  unsigned char *cm = (unsigned char *)(swi + g.ncell);           // [ncell]
+  const int W = c.W, H = c.H;
+  const double deg2rad = 0x1.1df46a2529d39p-6;                    // math.radians
+  const double depth2 = c.depth * c.depth;
+  const double inv_scale = 1.0 / c.scale;
+  const double *dr = s.drone + (size_t)e * D2D_DF;
+  const double x0 = dr[D2D_D_X], y0 = dr[D2D_D_Y], yaw = dr[D2D_D_YAW];
+  const int call = s.counters[(size_t)e * D2D_CF + D2D_C_STEPS] + 1;  // one plan() per step, before it
+  int *__restrict__ seen = p.seen_step + (size_t)e * W * H;
+  double *act = (double *)s.action;
+  if (call >= p.tobs_len) {  // refused by the host before the launch; never index past the table
+    if (lane == 0) act[e] = 0.0;
+    return;
+  }
+  const FastDiv fdb(g.bbn);
+  // ---- t_i: cells the current pose sees (yaw_planner.py:93-97); only the box around the drone can be seen ----
+  {
+    const double cy = d2d_cos(yaw * deg2rad), sy = -d2d_sin(yaw * deg2rad);  // :71
+    const int bi = (int)floor((x0 - c.depth) * inv_scale) - 1, bj = (int)floor((y0 - c.depth) * inv_scale) - 1;
+    for (int q0 = 0; q0 < g.ncell; q0 += WAVE) {
+      const int q = q0 + lane;
+      int r, cc;
+      fdb.divmod(q, r, cc);
+      const int i = bi + r, j = bj + cc;
+      if (q < g.ncell && i >= 0 && i < W && j >= 0 && j < H) {
+        if (view_cell(p, depth2, x0, y0, cy, sy, (double)i * c.scale, (double)j * c.scale)) seen[i * H + j] = call;
+      }
+    }
+  }
+  const int *hdr = p.traj_hdr + (size_t)e * 2;
+  const int head = hdr[0], n = hdr[1] - hdr[0];
+  if (n == 0) {  // :118-119
+    if (lane == 0) act[e] = 0.0;
+    return;
+  }
+  wave_sync_global();  // the candidates read the seen map the lanes just wrote
+  const double *__restrict__ traj = p.traj + (size_t)e * p.traj_cap * 4;
+  const double hx = traj[(size_t)head * 4], hy = traj[(size_t)head * 4 + 1];
+  const int bi = (int)floor((hx - c.depth) * inv_scale) - 1, bj = (int)floor((hy - c.depth) * inv_scale) - 1;
+  // ---- v_i: the swept map inside the box (last write wins = largest waypoint index), :88-90 ----
+  for (int q = lane; q < g.ncell; q += WAVE) swi[q] = -1;
+  wave_sync_lds();
+  for (int i0 = 0; i0 < n; i0 += WAVE) {
+    const int i = i0 + lane;
+    if (i < n) {
+      const double *w = traj + (size_t)(head + i) * 4;
+      const int ci = cell_fast(w[0], c.scale, inv_scale), cj = cell_fast(w[1], c.scale, inv_scale);
+      const int r = ci - bi, cc = cj - bj;
+      if (ci >= 0 && ci < W && cj >= 0 && cj < H && r >= 0 && r < g.bbn && cc >= 0 && cc < g.bbn) atomicMax(&swi[r * g.bbn + cc], i);
+    }
+  }
+  wave_sync_lds();
+  // ---- reward (:109-111) and the candidates' view bits for every box cell ----
+  double cyc[8], syc[8];
+#pragma unroll
+  for (int a = 0; a < 8; ++a) {
+    cyc[a] = 0.0;
+    syc[a] = 0.0;
+    if (a < p.n_yaw) {
+      const double ty = py_mod360(yaw + p.yaw_space[a] * c.dt);  // :114, Drone2D.__init__ `% 360` (utils.py:718)
+      cyc[a] = d2d_cos(ty * deg2rad);
+      syc[a] = -d2d_sin(ty * deg2rad);
+    }
+  }
+  for (int q0 = 0; q0 < g.ncell; q0 += WAVE) {
+    const int q = q0 + lane;
+    int r, cc;
+    fdb.divmod(q, r, cc);
+    const int i = bi + r, j = bj + cc;
+    if (q < g.ncell) {
+      double rw = 0.0;
+      unsigned int bits = 0;
+      if (i >= 0 && i < W && j >= 0 && j < H) {
+        const int sn = seen[i * H + j];
+        const double tobs = sn > 0 ? p.tobs_tab[call - sn] : p.tobs_tab[p.tobs_len + call];
+        const int si = swi[q];
+        const double sw = si >= 0 ? (double)si * c.dt : 0.0;
+        if (sw > 0.0 && sw <= 3.0 && tobs >= 0.5) rw = 1000000.0;
+        else if (sw > 3.0 && tobs >= 0.5) rw = 1000.0;
+        else rw = (1.0 * tobs < 1.0) ? 1.0 * tobs : 1.0;
+        const double x = (double)i * c.scale, y = (double)j * c.scale;
+#pragma unroll
+        for (int a = 0; a < 8; ++a)
+          if (a < p.n_yaw && view_cell(p, depth2, hx, hy, cyc[a], syc[a], x, y)) bits |= 1u << a;
+      }
+      rew[q] = rw;
+      cm[q] = (unsigned char)bits;
+    }
+  }
+  wave_sync_lds();
+  // ---- np.sum(view * reward) per candidate in numpy's pairwise order (:123) ----
+  // lane = (candidate a, accumulator r): block by block, elements off + r + 8 k; cells outside the box contribute 0
+  const int a_of = lane >> 3, r_of = lane & 7;
+  const FastDiv fdh(H);
+  for (int lf = 0; lf < p.pw_nleaf; ++lf) {
+    const int off = p.pw_leaf[2 * lf], m = p.pw_leaf[2 * lf + 1];
+    // rows of the box this block can touch at all
+    const int i_first = off / H, i_last = (off + m - 1) / H;
+    double acc = 0.0;
+    double res = 0.0;
+    if (i_last >= bi && i_first < bi + g.bbn) {
+      if (m < 8) {
+        if (r_of == 0 && a_of < p.n_yaw)
+          for (int k = 0; k < m; ++k) {
+            int gi, gj;
+            fdh.divmod(off + k, gi, gj);
+            const int r = gi - bi, cc = gj - bj;
+            if (r >= 0 && r < g.bbn && cc >= 0 && cc < g.bbn && ((cm[r * g.bbn + cc] >> a_of) & 1)) acc += rew[r * g.bbn + cc];
+          }
+        res = acc;
+      } else {
+        const int m8 = m - (m & 7);
+        for (int k = r_of; k < m8; k += 8) {
+          int gi, gj;
+          fdh.divmod(off + k, gi, gj);
+          const int r = gi - bi, cc = gj - bj;
+          if (a_of < p.n_yaw && r >= 0 && r < g.bbn && cc >= 0 && cc < g.bbn && ((cm[r * g.bbn + cc] >> a_of) & 1))
+            acc += rew[r * g.bbn + cc];
+        }
+        // ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7))
+        double v = acc + shfl_f64(acc, lane + 1);
+        v = v + shfl_f64(v, lane + 2);
+        v = v + shfl_f64(v, lane + 4);
+        res = v;
+        if (r_of == 0 && a_of < p.n_yaw)
+          for (int k = m8; k < m; ++k) {
+            int gi, gj;
+            fdh.divmod(off + k, gi, gj);
+            const int r = gi - bi, cc = gj - bj;
+            double x = 0.0;
+            if (r >= 0 && r < g.bbn && cc >= 0 && cc < g.bbn && ((cm[r * g.bbn + cc] >> a_of) & 1)) x = rew[r * g.bbn + cc];
+            res += x;
+          }
+      }
+    }
+    if (r_of == 0 && a_of < p.n_yaw) lsum[a_of * p.pw_nleaf + lf] = res;
+  }
+  wave_sync_lds();
+  // ---- the blocks' sums added in the recursion's order; argmax with strict >, default index 0 (:116-125) ----
+  double total = 0.0;
+  if (lane < p.n_yaw) {
+    double *st = stk + lane * 16;
+    int sp = 0;
+    for (int k = 0; k < p.pw_nprog; ++k) {
+      const int op = p.pw_prog[k];
+      if (op >= 0) st[sp++] = lsum[lane * p.pw_nleaf + op];
+      else {
+        sp -= 1;
+        st[sp - 1] = st[sp - 1] + st[sp];
+      }
+    }
+    total = st[0];
+  }
+  int best = 0;
+  double max_reward = 0.0;
+  for (int a = 0; a < p.n_yaw; ++a) {
+    const double r = shfl_f64(total, a);
+    if (max_reward < r) {
+      best = a;
+      max_reward = r;
+    }
+  }
+  if (lane == 0) act[e] = p.yaw_space[best] / p.yaw_rate_max;  // :127
+}
+
+// plugin state of the masked envs back to "fresh objects" (experiment.py:31-34)
+__global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK) void k_plan_reset(d2d_cfg c, d2d_plan p, const unsigned char *mask,
+                                                                      int mask_stride) {
+  const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
+  const int e = blockIdx.x * WAVES_PER_BLOCK + wv;
+  if (e >= c.B) return;
+  if (mask && !mask[(size_t)e * mask_stride]) return;
+  const size_t N = (size_t)(c.N > 0 ? c.N : 1), WH = (size_t)c.W * c.H;
+  if (p.traj_hdr && lane < 2) p.traj_hdr[(size_t)e * 2 + lane] = 0;
+  for (size_t k = lane; k < N; k += WAVE) {
+    if (p.trk_radius && p.trk_radius0) p.trk_radius[e * N + k] = p.trk_radius0[e * N + k];
+    if (p.trk_prev) p.trk_prev[e * N + k] = 0;
+  }
+  if (p.seen_step)
+    for (size_t i = lane; i < WH; i += WAVE) p.seen_step[e * WH + i] = 0;
+}
+
+__global__ void k_sincos(const double *in, double *so, double *co, long long n) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    so[i] = d2d_sin(in[i]);
+    co[i] = d2d_cos(in[i]);
+  }
+}

@@ -9,6 +9,9 @@ Planner modes
   'NoMove'    traj_planner.py:68-76 runs on the device (one launch per step)
   'external'  the caller supplies plan_ok / wp_valid / wp each step (host planner plugin between
               `perceive()` and `act()`, or replayed plans with the fused `step()`)
+  'Primitive' with `device_plugins=True`: traj_planner.py:78-233 runs on the device between the two halves of
+              the step; with `gaze='Oxford'` yaw_planner.py:41-127 supplies the action on the device as well
+              (`closed_loop()`: gaze -> perceive -> plan -> act, no host round trip)
 """
 import numpy as np
 import torch
@@ -41,7 +44,7 @@ def build_worlds(params, num_envs, env_offset=0, workers=0):
 
 class VecDrone2DEnv:
     def __init__(self, params, num_envs, device='cuda:0', planner=None, env_offset=0, backend=None,
-                 kf_enabled=True, worlds=None):
+                 kf_enabled=True, worlds=None, device_plugins=False, gaze=None):
         self.params = with_defaults(params)
         self.num_envs = int(num_envs)
         self.env_offset = int(env_offset)
@@ -67,6 +70,15 @@ class VecDrone2DEnv:
         self._st = self.state.struct()
         self._init_st = self.init_state.struct()
         self.reward = torch.zeros(self.num_envs, dtype=torch.float32, device=self.device)   # drone_v2.py:257
+        self.plugins = None
+        if device_plugins:
+            from .device_plugins import PluginState
+            gaze = gaze if gaze is not None else self.params.gaze_method
+            if planner not in ('Primitive', 'NoMove') or gaze not in ('Oxford', 'external', None):
+                raise NotImplementedError(f'device plugins: planner {planner!r} / gaze {gaze!r} (device: Primitive, NoMove / Oxford)')
+            self.plugins = PluginState(self.params, self.cfg, self.device, self.tracker_radius.numpy(),
+                                       planner=planner, gaze=gaze or 'external')
+            self._plan = self.plugins.struct()
 
     # ------------------------------------------------------------------ gym-like surface (batched)
     @property
@@ -78,6 +90,7 @@ class VecDrone2DEnv:
         if mask is not None:
             mask = mask.to(device=self.device, dtype=torch.uint8).contiguous()
         self.backend.reset(self.cfg, self._st, self._init_st, mask)
+        self.reset_plugins(mask)
         return {}
 
     def _set_action(self, actions):
@@ -177,6 +190,22 @@ class VecDrone2DEnv:
                 'flight_time': s.counters[:, A.C_STEPS].double() * self.cfg.dt,
                 'tracked_agent': s.counters[:, A.C_TRACKED], 'newly_tracked': s.newly, 'hit': s.hit}
         return obs, self.reward, done, info
+
+    def closed_loop(self, nsteps=1, auto_reset=False):
+        """`nsteps` reference-style steps with the plugins on the device: a = Oxford.plan(info); perceive;
+        Primitive.replan_check + plan; act (experiment.py:68-70).  With `auto_reset` an env whose episode ended
+        restarts from its seeded world with fresh plugin state before the next step."""
+        if self.plugins is None:
+            raise RuntimeError('closed_loop() needs device_plugins=True')
+        self.backend.closed_loop(self.cfg, self._st, self._plan, int(nsteps), auto_reset,
+                                 self._init_st if auto_reset else None)
+        return self._result()
+
+    def reset_plugins(self, mask=None):
+        if self.plugins is not None:
+            if mask is not None:
+                mask = mask.to(device=self.device, dtype=torch.uint8).contiguous()
+            self.backend.plan_reset(self.cfg, self._plan, mask, 1)
 
     def sync(self):
         self.backend.sync()

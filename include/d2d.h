@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define D2D_ABI_VERSION 4
+#define D2D_ABI_VERSION 5
 
 /* grid cell codes, utils.py:11-16 */
 #define D2D_UNEXPLORED 0
@@ -48,6 +48,12 @@ extern "C" {
 /* planner_mode */
 #define D2D_PLANNER_EXTERNAL 0 /* plan_ok / wp_valid / wp are inputs (host plugin or replay)          */
 #define D2D_PLANNER_NOMOVE 1   /* traj_planner.py:68-76 on device: ok, no waypoint, target=(-1,-1)    */
+/* d2d_plan.planner: which planner d2d_plan_stage runs between the two halves of the step */
+#define D2D_PLAN_NONE 0      /* plan_ok / wp_valid / wp stay as the caller wrote them                 */
+#define D2D_PLAN_PRIMITIVE 1 /* traj_planner.py:78-233: replan_check + motion-primitive A* on device  */
+/* d2d_plan.gaze: which gaze policy d2d_gaze_stage runs before the step */
+#define D2D_GAZE_NONE 0   /* action stays as the caller wrote it                                      */
+#define D2D_GAZE_OXFORD 1 /* yaw_planner.py:41-127 on device                                          */
 
 /* agent field planes of d2d_state.agents: [B][D2D_AF][N] */
 #define D2D_AF 6
@@ -158,6 +164,94 @@ typedef struct d2d_state {
   float *obs_yaw;      /* [B] obs['yaw_angle'] */
 } d2d_state;
 
+
+/* ---------------------------------------------------------------------------------------------
+ * Planner / gaze plugins on the device.  The reference calls them as Python
+ * objects around and inside step(): `a = policy.plan(info)` before the step (experiment.py:69),
+ * `planner.replan_check(drone)` + `planner.plan(drone, dt)` between perception and control
+ * (envs/drone_v2.py:194-197).  d2d_plan carries their constants, their per-env state and their scratch;
+ * d2d_cfg / d2d_state stay what the hot kernel takes by value.
+ *
+ * Constant tables are evaluated by the HOST with the very expressions the reference evaluates (numpy
+ * arange / Python float arithmetic), so the device only replays IEEE operations:
+ *   u_space   [nu]            Primitive.u_space (traj_planner.py:98-101)
+ *   sample_t  [n_sample][2]   t, t**2 for t in np.arange(0, 2, 2 / sample_num) (traj_planner.py:175-176)
+ *   traj_t    [n_ts][3]       t, t**2, 2 * t for t in np.arange(2, 0, -dt), stored in ASCENDING t (the
+ *                             reference builds the list backwards and reverses it, traj_planner.py:210-216)
+ *   yaw_space [n_yaw]         Oxford.v_yaw_space = np.arange(-w, w, w / 3) (yaw_planner.py:65)
+ *   tobs_tab  [2][tobs_len]   row 0: 0 + dt + dt + ... (k additions), row 1: 5 + dt + dt + ...: the value of a
+ *                             cell of Oxford.last_time_observed_map k calls after it was last seen / if it never
+ *                             was (yaw_planner.py:48,95-97); the map itself is kept as `seen_step`
+ *   pw_leaf   [pw_nleaf][2]   offset, length of the <= 128-element blocks numpy's pairwise summation cuts a
+ *   pw_prog   [pw_nprog]      W * H array into, and the order their partial sums are added in (>= 0: push
+ *                             block, -1: add the two on top) -- np.sum(view * reward), yaw_planner.py:123
+ *   acos_key_lo / acos_mask   np.arccos(q) <= half_fov for the 64 consecutive doubles q starting at the one whose
+ *                             ordered bit pattern is acos_key_lo (bit i of the mask = decision for the i-th);
+ *                             every q above the window is inside the cone, every q below outside.  numpy's
+ *                             arccos is a SIMD routine that differs from libm by an ulp; the window is how the
+ *                             host hands its own arccos to the device (yaw_planner.py:77).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct d2d_plan {
+  int32_t planner;  /* D2D_PLAN_* */
+  int32_t gaze;     /* D2D_GAZE_* */
+  int32_t nu;
+  int32_t n_sample;
+  int32_t n_ts;
+  int32_t max_itr;  /* 100: the search gives up at itr >= max_itr (traj_planner.py:149) */
+  int32_t traj_cap; /* waypoints per env in `traj` (>= (max_itr - 1) * n_ts can never overflow) */
+  int32_t node_cap; /* search nodes per env in `nodes` */
+  int32_t hash_cap; /* slots per env in `hash`, a power of two > node_cap */
+  int32_t n_yaw;
+  int32_t pw_nleaf;
+  int32_t pw_nprog;
+  int32_t tobs_len;
+  int32_t reserved;
+  double horizon;      /* Primitive.dt = 2 (traj_planner.py:103) */
+  double vmax;         /* drone_max_speed (traj_planner.py:172) */
+  double safe_dist;    /* drone_radius + 10 (traj_planner.py:32) */
+  double goal_tol;     /* search_threshold = 10 (traj_planner.py:106,158) */
+  double agent_radius; /* params.agent_radius: KalmanFilter.radius after an archive (utils.py:184) */
+  double half_fov;     /* math.radians(drone_view_range / 2) (yaw_planner.py:72) */
+  double yaw_rate_max; /* drone_max_yaw_speed (yaw_planner.py:127) */
+  int64_t acos_key_lo;
+  uint64_t acos_mask;
+  /* ---- constant tables (read only) ---- */
+  const double *u_space;
+  const double *sample_t;
+  const double *traj_t;
+  const double *yaw_space;
+  const double *tobs_tab;
+  const int32_t *pw_leaf;
+  const int32_t *pw_prog;
+  const double *trk_radius0; /* [B][N] tracker radii of the initial world: the reset source of trk_radius */
+  /* ---- per-env plugin state (read + written) ---- */
+  double *traj;         /* [B][traj_cap][4] planner.trajectory: position(2), velocity(2); accelerations are 0 */
+  int32_t *traj_hdr;    /* [B][2] index of the head waypoint, number of waypoints stored (len = stored - head) */
+  double *trk_radius;   /* [B][N] drone.trackers[k].radius (envs/drone_v2.py:46; back to agent_radius on archive) */
+  uint8_t *trk_prev;    /* [B][N] tracker.active as the planner stage last saw it (detects the archive) */
+  int32_t *seen_step;   /* [B][W][H] Oxford: number of the plan() call that last saw the cell, 0 = never */
+  /* ---- scratch of the search (contents meaningless between calls) ---- */
+  double *nodes;        /* [B][node_cap][D2D_NODE_F] */
+  int32_t *hash;        /* [B][hash_cap] */
+  /* ---- diagnostics ---- */
+  int32_t *plan_stat;   /* [B][4] searches run, expansions of the last search, nodes of the last search,
+                           capacity overflow flag (sticky; a search that overflowed reports failure) */
+} d2d_plan;
+
+/* one search node: position(2), velocity(2), cost, total_cost, acc(2), then parent slot / itr / key as raw bits */
+#define D2D_NODE_F 12
+#define D2D_N_PX 0
+#define D2D_N_PY 1
+#define D2D_N_VX 2
+#define D2D_N_VY 3
+#define D2D_N_COST 4
+#define D2D_N_TOTAL 5
+#define D2D_N_AX 6
+#define D2D_N_AY 7
+#define D2D_N_LINK 8  /* int32 parent slot, int32 itr */
+#define D2D_N_KEY 9   /* int64 packed index (cell x, cell y, round vx, round vy), traj_planner.py:93 */
+#define D2D_N_STATE 10 /* int64: 1 open, 2 closed */
+
 /* ---------------------------------------------------------------------------------------------
  * Entry points of libd2d_hip.so (gym-drone2d-activeperception_amd/csrc).  liboracle exports the
  * same set with the prefix d2d_oracle_ and ignores `stream`.
@@ -202,6 +296,36 @@ int d2d_reset(const d2d_cfg *cfg, const d2d_state *st, const d2d_state *init, co
 /* Device restatement of the host libm tan() the reference's math.tan resolves to (utils.py:640):
  * out[i] = tan(in[i]) for |in[i]| <= 25, bit-for-bit glibc 2.35 x86-64 FMA variant.  Test hook. */
 int d2d_tan_array(const double *in, double *out, int64_t n, void *stream);
+
+
+/* policy.plan(info) of the gaze plugin for every env (experiment.py:69), run BEFORE the step on the state the
+ * previous step left: writes st->action.  D2D_GAZE_OXFORD: yaw_planner.py:81-127 (view map of the current pose,
+ * time-since-observed map, swept-trajectory reward, 6 yaw-rate candidates).  D2D_GAZE_NONE: no-op. */
+int d2d_gaze_stage(const d2d_cfg *cfg, const d2d_state *st, const d2d_plan *plan, void *stream);
+
+/* planner.replan_check(drone) + planner.plan(drone, dt) (envs/drone_v2.py:194-197) + the head waypoint
+ * step_pos will consume (utils.py:733-739), run BETWEEN d2d_perceive and d2d_act: writes st->plan_ok,
+ * st->wp_valid, st->wp (the caller's buffers behind those const pointers) and pops the head.
+ * D2D_PLAN_PRIMITIVE: traj_planner.py:125-233.  D2D_PLAN_NONE: no-op. */
+int d2d_plan_stage(const d2d_cfg *cfg, const d2d_state *st, const d2d_plan *plan, void *stream);
+
+/* One closed-loop step with the plugins on the device: gaze -> perceive -> plan -> act, queued on `stream`
+ * (the reference's `a = policy.plan(info); env.step(a)`, experiment.py:68-70).  `nsteps` of them back to back;
+ * with `auto_reset` != 0 every env whose step ended the episode (flags[D2D_F_DONE]) is put back to the snapshot
+ * `init` (and its plugin state cleared) before the next step, the way the reference's sweeps start the next
+ * episode (main.py:26-57); `init` may be NULL when auto_reset == 0. */
+int d2d_closed_loop(const d2d_cfg *cfg, const d2d_state *st, const d2d_plan *plan, int32_t nsteps,
+                    int32_t auto_reset, const d2d_state *init, void *stream);
+
+/* Clears the plugin state (trajectory, tracker radii <- plan->trk_radius0, seen map) of the envs with
+ * mask[e * mask_stride] != 0 (mask == NULL: all): Experiment.__init__ builds fresh plugin objects per episode
+ * (experiment.py:31-34). */
+int d2d_plan_reset(const d2d_cfg *cfg, const d2d_plan *plan, const uint8_t *mask, int32_t mask_stride,
+                   void *stream);
+
+/* Device restatement of the host libm sin() / cos() the reference's math.sin / math.cos resolve to
+ * (yaw_planner.py:71): bit-for-bit glibc 2.35 x86-64 FMA variant for |x| < 105414350.  Test hook. */
+int d2d_sincos_array(const double *in, double *sin_out, double *cos_out, int64_t n, void *stream);
 
 #ifdef __cplusplus
 }

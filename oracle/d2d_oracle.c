@@ -18,6 +18,7 @@
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../include/d2d.h"
@@ -63,6 +64,11 @@ static double py_mod(double a, double b) {
 }
 
 static int cell_of(double v, double scale) { return (int)py_floordiv(v, scale); }
+
+/* numpy.linalg.norm of a 2-vector: sqrt(x.dot(x)), and the bundled OpenBLAS ddot evaluates the two-element dot
+ * product as fma(x1, x1, x0 * x0) on FMA hardware (measured against numpy: 20000/20000 bit-identical; the unfused
+ * sum matches only 92 %).  Call sites: utils.py:476,756,760,774, envs/drone_v2.py:223-224, traj_planner.py:58,88,158,172,228. */
+static double norm2(double x, double y) { return sqrt(fma(y, y, x * x)); }
 
 typedef struct env_view {
   const d2d_cfg *c;
@@ -137,7 +143,7 @@ static void st_agents(env_view *v) {
     double nx = px[k] + velx * c->dt, ny = py[k] + vely * c->dt;
     int aliased = 1;
     double pvx = velx, pvy = vely;
-    if (sqrt(velx * velx + vely * vely) <= 5.0) {
+    if (norm2(velx, vely) <= 5.0) {
       /* pref_velocity rebound to a fresh array: Rot(+30 deg) @ pref; velocity keeps the old array */
       /* numpy's 2x2 @ 2x1 goes through the bundled OpenBLAS dgemv, which evaluates each row as
        * fma(M[r][0], v0, M[r][1] * v1) on FMA hardware (measured: 40000/40000 rows bit-identical;
@@ -366,7 +372,7 @@ static void st_control(env_view *v, const d2d_state *s) {
   }
   double *d = v->dr;
   if (!ok) {
-    double n = sqrt(d[D2D_D_VX] * d[D2D_D_VX] + d[D2D_D_VY] * d[D2D_D_VY]);
+    double n = norm2(d[D2D_D_VX], d[D2D_D_VY]);
     if (n <= c->max_acc * c->dt) {
       d[D2D_D_VX] = 0;
       d[D2D_D_VY] = 0;
@@ -408,7 +414,7 @@ static void st_collide(env_view *v) {
   if (!col)
     for (int k = 0; k < N; ++k) {
       double dx = px[k] - x, dy = py[k] - y;
-      if (sqrt(dx * dx + dy * dy) < rr[k] + R) {
+      if (norm2(dx, dy) < rr[k] + R) {
         col = 2;
         break;
       }
@@ -416,8 +422,8 @@ static void st_collide(env_view *v) {
   int dead = 0, frz = 0;
   if (col == 0) {
     double gx = x - v->tgt[0], gy = y - v->tgt[1];
-    if (sqrt(gx * gx + gy * gy) <= 10) v->cnt[D2D_C_SM] = D2D_SM_GOAL_REACHED;
-    double vn = sqrt(v->dr[D2D_D_VX] * v->dr[D2D_D_VX] + v->dr[D2D_D_VY] * v->dr[D2D_D_VY]);
+    if (norm2(gx, gy) <= 10) v->cnt[D2D_C_SM] = D2D_SM_GOAL_REACHED;
+    double vn = norm2(v->dr[D2D_D_VX], v->dr[D2D_D_VY]);
     dead = (v->cnt[D2D_C_FAIL] >= 10 && vn == 0) ? 1 : 0;
     frz = ((double)v->cnt[D2D_C_STEPS] >= c->max_steps && !dead) ? 1 : 0;
   }
@@ -546,5 +552,507 @@ int d2d_oracle_reset(const d2d_cfg *c, const d2d_state *s, const d2d_state *init
 int d2d_oracle_tan_array(const double *in, double *out, int64_t n, void *stream) {
   (void)stream;
   for (int64_t i = 0; i < n; ++i) out[i] = tan(in[i]);
+  return 0;
+}
+
+/* =================================================================================================
+ * Planner / gaze plugins: Primitive (traj_planner.py:78-233) and Oxford
+ * (yaw_planner.py:41-127), restated scalar and literal.  Same status as the rest of this file: TEST
+ * INFRASTRUCTURE, pinned by the reference's own episodes (the Primitive traces under tests/golden record the action,
+ * plan result, head waypoint and trajectory length of every step of the imported reference).
+ *
+ * numpy roundings that matter here, each measured against numpy 2.2.6 + its bundled OpenBLAS in the build
+ * container (100000 / 100000 bit-identical, tools in DESIGN.md section 4):
+ *   np.array([1, t, t**2]) @ coeff.T            = fma(t**2, a/2, p + t * v)            (traj_planner.py:121,176)
+ *   np.array([1, 2*t]) @ coeff[:, 1:].T         = v + (2*t) * (a/2)                    (traj_planner.py:122)
+ *   np.array([1, H, H**2]) @ [[p],[v],[a/2]]    = (p + 2 * v) + 4 * (a/2)              (traj_planner.py:182)
+ *   np.array([1, 2*H]) @ [[v],[a/2]]            = v + 4 * (a/2)                        (traj_planner.py:172,183)
+ *   norm(2-vector)                              = sqrt(fma(y, y, x * x))               (norm2 above)
+ *   np.sum(W x H float64)                       = pairwise summation (d2d_plan.pw_leaf / pw_prog)
+ *   np.arccos(q) <= half_fov                    = d2d_plan.acos_key_lo / acos_mask (numpy's arccos is a SIMD
+ *                                                 routine, not libm's; the host tabulates its decisions)
+ * ================================================================================================= */
+
+static uint8_t dm_get_grid(const env_view *v, double x, double y) { /* drone.map.get_grid, utils.py:545-548 */
+  const d2d_cfg *c = v->c;
+  if (x >= c->W_px || x < 0 || y >= c->H_px || y < 0) return 1;
+  return v->dm[(size_t)cell_of(x, c->scale) * c->H + cell_of(y, c->scale)];
+}
+
+typedef struct plan_view {
+  const d2d_plan *p;
+  double *traj;      /* [traj_cap][4] */
+  int32_t *hdr;      /* head, stored */
+  double *trk_radius;
+  uint8_t *trk_prev;
+  int32_t *seen;
+  double *nodes;
+  int32_t *hash;
+  int32_t *stat;
+} plan_view;
+
+static plan_view pview(const d2d_cfg *c, const d2d_plan *p, int e) {
+  plan_view q;
+  size_t N = (size_t)(c->N > 0 ? c->N : 1);
+  q.p = p;
+  q.traj = p->traj + (size_t)e * p->traj_cap * 4;
+  q.hdr = p->traj_hdr + (size_t)e * 2;
+  q.trk_radius = p->trk_radius + (size_t)e * N;
+  q.trk_prev = p->trk_prev + (size_t)e * N;
+  q.seen = p->seen_step + (size_t)e * c->W * c->H;
+  q.nodes = p->nodes + (size_t)e * p->node_cap * D2D_NODE_F;
+  q.hash = p->hash + (size_t)e * p->hash_cap;
+  q.stat = p->plan_stat + (size_t)e * 4;
+  return q;
+}
+
+/* Planner.is_free, traj_planner.py:28-59 */
+static int is_free(const env_view *v, const plan_view *q, double x, double y, double t) {
+  const d2d_cfg *c = v->c;
+  if (isnan(x) || isnan(y)) return 0;
+  const double d = q->p->safe_dist;
+  if (dm_get_grid(v, x - d, y) == 1) return 0;
+  if (dm_get_grid(v, x, y) == 1) return 0;
+  if (dm_get_grid(v, x + d, y) == 1) return 0;
+  if (dm_get_grid(v, x, y - d) == 1) return 0;
+  if (dm_get_grid(v, x, y + d) == 1) return 0;
+  for (int k = 0; k < c->N; ++k)
+    if (v->active[k]) {
+      const double *mu = v->kf + (size_t)k * D2D_KF;
+      double ex = mu[0] + t * mu[2], ey = mu[1] + t * mu[3]; /* estimate_pos, utils.py:220-223 */
+      if (norm2(x - ex, y - ey) <= c->drone_radius + q->trk_radius[k] + 5 + c->sigma) return 0;
+    }
+  return 1;
+}
+
+static int64_t py_ifloordiv(int64_t a, int64_t b) { /* Python int // for b > 0 */
+  int64_t d = a / b;
+  if ((a % b != 0) && (a < 0)) --d;
+  return d;
+}
+
+/* Primitive_Node.get_index, traj_planner.py:93: (round(x) // 10, round(y) // 10, round(vx), round(vy)) */
+static int64_t node_key(double px, double py, double vx, double vy) {
+  int64_t a = py_ifloordiv((int64_t)rint(px), 10), b = py_ifloordiv((int64_t)rint(py), 10);
+  int64_t cc = (int64_t)rint(vx), d = (int64_t)rint(vy);
+  return (int64_t)((((uint64_t)(a + 32768) & 0xffff) << 48) | (((uint64_t)(b + 32768) & 0xffff) << 32) |
+                   (((uint64_t)(cc + 32768) & 0xffff) << 16) | ((uint64_t)(d + 32768) & 0xffff));
+}
+
+static void node_set_i64(double *slot, int64_t x) { memcpy(slot, &x, 8); }
+static int64_t node_get_i64(const double *slot) {
+  int64_t x;
+  memcpy(&x, slot, 8);
+  return x;
+}
+
+static uint32_t key_hash(int64_t k) {
+  uint64_t x = (uint64_t)k * 0x9E3779B97F4A7C15ull;
+  return (uint32_t)(x >> 32);
+}
+
+/* slot of `key` in the env's table, or -1 */
+static int hash_find(const plan_view *q, int64_t key) {
+  uint32_t m = (uint32_t)q->p->hash_cap - 1, h = key_hash(key) & m;
+  for (;;) {
+    int32_t s = q->hash[h];
+    if (s == 0) return -1;
+    if (node_get_i64(q->nodes + (size_t)(s - 1) * D2D_NODE_F + D2D_N_KEY) == key) return s - 1;
+    h = (h + 1) & m;
+  }
+}
+
+static void hash_put(const plan_view *q, int64_t key, int slot) {
+  uint32_t m = (uint32_t)q->p->hash_cap - 1, h = key_hash(key) & m;
+  while (q->hash[h] != 0) h = (h + 1) & m;
+  q->hash[h] = slot + 1;
+}
+
+static void node_write(const env_view *v, double *nd, double px, double py, double vx, double vy, double cost, double ax,
+                       double ay, int parent, int itr) {
+  nd[D2D_N_PX] = px;
+  nd[D2D_N_PY] = py;
+  nd[D2D_N_VX] = vx;
+  nd[D2D_N_VY] = vy;
+  nd[D2D_N_COST] = cost;
+  /* traj_planner.py:88 */
+  nd[D2D_N_TOTAL] = cost + 0.5 * norm2(px - v->tgt[0], py - v->tgt[1]) + 0.1 * norm2(vx, vy);
+  nd[D2D_N_AX] = ax;
+  nd[D2D_N_AY] = ay;
+  int32_t link[2] = {parent, itr};
+  memcpy(nd + D2D_N_LINK, link, 8);
+  node_set_i64(nd + D2D_N_KEY, node_key(px, py, vx, vy));
+  node_set_i64(nd + D2D_N_STATE, 1);
+}
+
+/* Primitive.plan, traj_planner.py:125-218.  The open set is a Python dict: iteration order = order of first
+ * insertion of each key, a replaced value keeps its place; min() returns the first minimal entry.  Slots are
+ * appended in insertion order and closed in place, which is exactly that order. */
+static int primitive_search(const env_view *v, const plan_view *q) {
+  const d2d_plan *p = q->p;
+  const double H = p->horizon;
+  memset(q->hash, 0, sizeof(int32_t) * (size_t)p->hash_cap);
+  int nn = 0, open_n = 0, goal = -1, itr = 0, expansions = 0, overflow = 0;
+  node_write(v, q->nodes, v->dr[D2D_D_X], v->dr[D2D_D_Y], v->dr[D2D_D_VX], v->dr[D2D_D_VY], 0.0, 0.0, 0.0, -1, 0);
+  hash_put(q, node_get_i64(q->nodes + D2D_N_KEY), 0);
+  nn = 1;
+  open_n = 1;
+  for (;;) {
+    itr += 1;
+    if (open_n == 0 || itr >= p->max_itr) break;
+    int cur = -1;
+    double best = 0;
+    for (int s = 0; s < nn; ++s) {
+      const double *nd = q->nodes + (size_t)s * D2D_NODE_F;
+      if (node_get_i64(nd + D2D_N_STATE) != 1) continue;
+      if (cur < 0 || nd[D2D_N_TOTAL] < best) {
+        cur = s;
+        best = nd[D2D_N_TOTAL];
+      }
+    }
+    double *cn = q->nodes + (size_t)cur * D2D_NODE_F;
+    const double px = cn[D2D_N_PX], py = cn[D2D_N_PY], vx = cn[D2D_N_VX], vy = cn[D2D_N_VY], ccost = cn[D2D_N_COST];
+    int32_t link[2];
+    memcpy(link, cn + D2D_N_LINK, 8);
+    const int citr = link[1];
+    if (norm2(px - v->tgt[0], py - v->tgt[1]) <= p->goal_tol) {
+      goal = cur;
+      break;
+    }
+    node_set_i64(cn + D2D_N_STATE, 2);
+    open_n -= 1;
+    expansions += 1;
+    for (int ia = 0; ia < p->nu && !overflow; ++ia)
+      for (int ja = 0; ja < p->nu; ++ja) {
+        const double ax = p->u_space[ia], ay = p->u_space[ja];
+        const double hx = ax / 2, hy = ay / 2;
+        const double vex = vx + (2 * H) * hx, vey = vy + (2 * H) * hy; /* :172,183 */
+        if (!(norm2(vex, vey) < p->vmax)) continue;
+        int ok = 1;
+        for (int sidx = 0; sidx < p->n_sample; ++sidx) { /* :175-180 */
+          const double t = p->sample_t[2 * sidx], t2 = p->sample_t[2 * sidx + 1];
+          const double sx = rint(fma(t2, hx, px + t * vx)), sy = rint(fma(t2, hy, py + t * vy));
+          if (!is_free(v, q, sx, sy, t + citr * H)) {
+            ok = 0;
+            break;
+          }
+        }
+        if (!ok) continue;
+        const double ex = rint((px + H * vx) + (H * H) * hx), ey = rint((py + H * vy) + (H * H) * hy); /* :182 */
+        const double cost = ccost + (ax * ax + ay * ay) / 100 + 10;                                   /* :184 */
+        double tmp[D2D_NODE_F];
+        node_write(v, tmp, ex, ey, vex, vey, cost, ax, ay, cur, citr + 1);
+        /* :192-202, applied successor by successor in generation order */
+        const int64_t key = node_get_i64(tmp + D2D_N_KEY);
+        const int s = hash_find(q, key);
+        if (s >= 0) {
+          double *nd = q->nodes + (size_t)s * D2D_NODE_F;
+          if (node_get_i64(nd + D2D_N_STATE) == 2) continue;
+          if (nd[D2D_N_COST] > cost) memcpy(nd, tmp, sizeof tmp);
+        } else {
+          if (nn >= p->node_cap) {
+            overflow = 1;
+            break;
+          }
+          memcpy(q->nodes + (size_t)nn * D2D_NODE_F, tmp, sizeof tmp);
+          hash_put(q, key, nn);
+          nn += 1;
+          open_n += 1;
+        }
+      }
+    if (overflow) break;
+  }
+  q->stat[0] += 1;
+  q->stat[1] = expansions;
+  q->stat[2] = nn;
+  if (overflow) q->stat[3] = 1;
+  q->hdr[0] = 0;
+  q->hdr[1] = 0;
+  if (goal < 0 || overflow) return 0;
+  /* :207-216: waypoints of every primitive from the goal back to the start, then reversed */
+  int depth = 0;
+  for (int s = goal; s != 0;) {
+    int32_t link[2];
+    memcpy(link, q->nodes + (size_t)s * D2D_NODE_F + D2D_N_LINK, 8);
+    s = link[0];
+    depth += 1;
+  }
+  if (depth * p->n_ts > p->traj_cap) {
+    q->stat[3] = 1;
+    return 0;
+  }
+  int s = goal;
+  for (int lvl = depth - 1; lvl >= 0; --lvl) {
+    const double *nd = q->nodes + (size_t)s * D2D_NODE_F;
+    int32_t link[2];
+    memcpy(link, nd + D2D_N_LINK, 8);
+    const double *pn = q->nodes + (size_t)link[0] * D2D_NODE_F;
+    const double hx = nd[D2D_N_AX] / 2, hy = nd[D2D_N_AY] / 2;
+    for (int m = 0; m < p->n_ts; ++m) {
+      const double t = p->traj_t[3 * m], t2 = p->traj_t[3 * m + 1], tt = p->traj_t[3 * m + 2];
+      double *w = q->traj + ((size_t)lvl * p->n_ts + m) * 4;
+      w[0] = rint(fma(t2, hx, pn[D2D_N_PX] + t * pn[D2D_N_VX])); /* :121 */
+      w[1] = rint(fma(t2, hy, pn[D2D_N_PY] + t * pn[D2D_N_VY]));
+      w[2] = pn[D2D_N_VX] + tt * hx;                             /* :122 */
+      w[3] = pn[D2D_N_VY] + tt * hy;
+    }
+    s = link[0];
+  }
+  q->hdr[1] = depth * p->n_ts;
+  return 1;
+}
+
+/* Primitive.replan_check, traj_planner.py:220-233; returns 1 when the trajectory was cleared */
+static int replan_check(const env_view *v, const plan_view *q) {
+  const d2d_cfg *c = v->c;
+  const int head = q->hdr[0], n = q->hdr[1] - q->hdr[0];
+  int clear = 0, swept_wall = 0;
+  for (int i = 0; i < n && !clear; ++i) {
+    const double *w = q->traj + (size_t)(head + i) * 4;
+    const double ti = i * c->dt;
+    const int ci = cell_of(w[0], c->scale), cj = cell_of(w[1], c->scale);
+    /* swep_map is uint8: the stored value is trunc(i * dt); np.sum(where(occ == 1) * swep) > 0 asks for one
+     * trajectory cell with a non-zero stored value on a wall (later visits only raise the value) */
+    if (ci >= 0 && ci < c->W && cj >= 0 && cj < c->H && (uint8_t)ti > 0 && v->dm[(size_t)ci * c->H + cj] == D2D_OCCUPIED)
+      swept_wall = 1;
+    for (int k = 0; k < c->N; ++k)
+      if (v->active[k]) {
+        const double *mu = v->kf + (size_t)k * D2D_KF;
+        double ex = mu[0] + ti * mu[2], ey = mu[1] + ti * mu[3];
+        if (norm2(ex - w[0], ey - w[1]) <= c->drone_radius + q->trk_radius[k]) {
+          clear = 1;
+          break;
+        }
+      }
+  }
+  if (clear || swept_wall) {
+    q->hdr[0] = 0;
+    q->hdr[1] = 0;
+    return 1;
+  }
+  return 0;
+}
+
+static int plan_check(const d2d_cfg *c, const d2d_state *s, const d2d_plan *p) {
+  int rc = check(c, s);
+  if (rc) return rc;
+  if (!p) return fail(-1, "null plan");
+  if (p->planner == D2D_PLAN_PRIMITIVE || p->gaze == D2D_GAZE_OXFORD) {
+    if (!p->traj || !p->traj_hdr) return fail(-1, "plan: null trajectory buffers");
+    if (!c->kf_enabled) return fail(-4, "device plugins need the Kalman trackers on the device (kf_enabled)");
+  }
+  if (p->planner == D2D_PLAN_PRIMITIVE) {
+    if (!p->u_space || !p->sample_t || !p->traj_t || !p->trk_radius || !p->trk_prev || !p->nodes || !p->hash || !p->plan_stat)
+      return fail(-1, "plan: null planner pointer");
+    if (p->hash_cap <= p->node_cap || (p->hash_cap & (p->hash_cap - 1))) return fail(-1, "plan: hash_cap must be a power of two > node_cap");
+    if (!s->plan_ok || !s->wp_valid || !s->wp) return fail(-1, "plan: plan_ok / wp_valid / wp buffers missing");
+  }
+  if (p->gaze == D2D_GAZE_OXFORD) {
+    if (!p->yaw_space || !p->tobs_tab || !p->pw_leaf || !p->pw_prog || !p->seen_step) return fail(-1, "plan: null gaze pointer");
+    if (!s->action) return fail(-1, "plan: null action buffer");
+  }
+  return 0;
+}
+
+int d2d_oracle_plan_stage(const d2d_cfg *c, const d2d_state *s, const d2d_plan *p, void *stream) {
+  (void)stream;
+  int rc = plan_check(c, s, p);
+  if (rc) return rc;
+  if (p->planner != D2D_PLAN_PRIMITIVE) return 0;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(g_threads > 0 ? g_threads : 1)
+  for (int e = 0; e < c->B; ++e) {
+    env_view v = view(c, s, e);
+    plan_view q = pview(c, p, e);
+    /* KalmanFilter.__init__ on archive puts tracker.radius back to params.agent_radius (utils.py:184,238) */
+    for (int k = 0; k < c->N; ++k) {
+      if (q.trk_prev[k] && !v.active[k]) q.trk_radius[k] = p->agent_radius;
+      q.trk_prev[k] = v.active[k];
+    }
+    replan_check(&v, &q);                                    /* drone_v2.py:194 */
+    int ok = 1;
+    if (q.hdr[1] - q.hdr[0] == 0) ok = primitive_search(&v, &q); /* drone_v2.py:197, traj_planner.py:128-129 */
+    uint8_t *plan_ok = (uint8_t *)s->plan_ok, *wp_valid = (uint8_t *)s->wp_valid;
+    double *wp = (double *)s->wp + (size_t)e * 6;
+    plan_ok[e] = (uint8_t)ok;
+    if (q.hdr[1] - q.hdr[0] > 0) { /* step_pos, utils.py:733-739 */
+      const double *w = q.traj + (size_t)q.hdr[0] * 4;
+      wp[0] = w[0]; wp[1] = w[1]; wp[2] = w[2]; wp[3] = w[3]; wp[4] = 0; wp[5] = 0;
+      wp_valid[e] = 1;
+      q.hdr[0] += 1;
+    } else {
+      wp_valid[e] = 0;
+      for (int i = 0; i < 6; ++i) wp[i] = 0;
+    }
+  }
+  return 0;
+}
+
+/* ---- Oxford, yaw_planner.py:41-127 ---- */
+static int64_t dkey(double x) {
+  int64_t b;
+  memcpy(&b, &x, 8);
+  return b ^ ((b >> 63) & 0x7FFFFFFFFFFFFFFFll);
+}
+
+static int acos_le(const d2d_plan *p, double q) { /* np.arccos(q) <= view_angle, yaw_planner.py:77 */
+  if (!(fabs(q) <= 1.0)) return 0;                 /* arccos is NaN there and the comparison false */
+  int64_t k = dkey(q);
+  if (k >= p->acos_key_lo + 64) return 1;
+  if (k < p->acos_key_lo) return 0;
+  return (int)((p->acos_mask >> (k - p->acos_key_lo)) & 1);
+}
+
+/* Oxford.get_view_map, yaw_planner.py:67-79, for cell (i, j) */
+static int view_cell(const d2d_cfg *c, const d2d_plan *p, double x0, double y0, double cy, double sy, int i, int j) {
+  const double x = (double)i * c->scale, y = (double)j * c->scale;
+  const double a = x0 - x, b = y0 - y;
+  const double d2 = a * a + b * b;
+  if (d2 <= 0) return 1;
+  const double q = ((x - x0) * cy + (y - y0) * sy) / sqrt(d2);
+  return acos_le(p, q) && d2 <= c->depth * c->depth;
+}
+
+static double pw_leaf_sum(const double *a, int m) {
+  if (m < 8) {
+    double r = 0;
+    for (int i = 0; i < m; ++i) r += a[i];
+    return r;
+  }
+  double r[8];
+  for (int j = 0; j < 8; ++j) r[j] = a[j];
+  int i = 8;
+  for (; i < m - (m % 8); i += 8)
+    for (int j = 0; j < 8; ++j) r[j] += a[i + j];
+  double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+  for (; i < m; ++i) res += a[i];
+  return res;
+}
+
+static double pw_sum(const d2d_plan *p, const double *a) {
+  double st[64];
+  int sp = 0;
+  for (int k = 0; k < p->pw_nprog; ++k) {
+    int op = p->pw_prog[k];
+    if (op >= 0) st[sp++] = pw_leaf_sum(a + p->pw_leaf[2 * op], p->pw_leaf[2 * op + 1]);
+    else {
+      sp -= 1;
+      st[sp - 1] = st[sp - 1] + st[sp];
+    }
+  }
+  return st[0];
+}
+
+int d2d_oracle_gaze_stage(const d2d_cfg *c, const d2d_state *s, const d2d_plan *p, void *stream) {
+  (void)stream;
+  int rc = plan_check(c, s, p);
+  if (rc) return rc;
+  if (p->gaze != D2D_GAZE_OXFORD) return 0;
+  const double deg2rad = M_PI / 180.0; /* math.radians */
+  const int WH = c->W * c->H;
+  int bad = 0;
+#pragma omp parallel for schedule(static) num_threads(g_threads > 0 ? g_threads : 1)
+  for (int e = 0; e < c->B; ++e) {
+    env_view v = view(c, s, e);
+    plan_view q = pview(c, p, e);
+    double *sw = (double *)malloc(sizeof(double) * WH * 2), *rew = sw + WH;
+    const int call = v.cnt[D2D_C_STEPS] + 1; /* one plan() per step, before it (experiment.py:68-70) */
+    if (call >= p->tobs_len) {
+#pragma omp atomic write
+      bad = 1;
+      free(sw);
+      continue;
+    }
+    const int head = q.hdr[0], n = q.hdr[1] - q.hdr[0];
+    for (int i = 0; i < WH; ++i) sw[i] = 0;
+    for (int i = 0; i < n; ++i) { /* :88-90 */
+      const double *w = q.traj + (size_t)(head + i) * 4;
+      const int ci = cell_of(w[0], c->scale), cj = cell_of(w[1], c->scale);
+      if (ci >= 0 && ci < c->W && cj >= 0 && cj < c->H) sw[ci * c->H + cj] = i * c->dt;
+    }
+    const double x0 = v.dr[D2D_D_X], y0 = v.dr[D2D_D_Y], yaw = v.dr[D2D_D_YAW];
+    {
+      const double cy = cos(yaw * deg2rad), sy = -sin(yaw * deg2rad); /* :71 */
+      for (int i = 0; i < c->W; ++i)
+        for (int j = 0; j < c->H; ++j)
+          if (view_cell(c, p, x0, y0, cy, sy, i, j)) q.seen[i * c->H + j] = call; /* :93-97 */
+    }
+    for (int i = 0; i < WH; ++i) { /* :109-111 */
+      const double tobs = q.seen[i] > 0 ? p->tobs_tab[call - q.seen[i]] : p->tobs_tab[p->tobs_len + call];
+      const double w = sw[i];
+      if (w > 0 && w <= 3 && tobs >= 0.5) rew[i] = 1000000;
+      else if (w > 3 && tobs >= 0.5) rew[i] = 1000;
+      else rew[i] = (1 * tobs < 1) ? 1 * tobs : 1; /* np.clip(c3 * t, -inf, 1) */
+    }
+    double *act = (double *)s->action;
+    if (n == 0) { /* :118-119 */
+      act[e] = 0;
+      free(sw);
+      continue;
+    }
+    const double hx = q.traj[(size_t)head * 4], hy = q.traj[(size_t)head * 4 + 1];
+    int best = 0;
+    double max_reward = 0;
+    double *prod = sw; /* the swept map is not needed any more */
+    for (int a = 0; a < p->n_yaw; ++a) { /* :121-125 */
+      const double ty = py_mod(yaw + p->yaw_space[a] * c->dt, 360.0);
+      const double cy = cos(ty * deg2rad), sy = -sin(ty * deg2rad);
+      for (int i = 0; i < c->W; ++i)
+        for (int j = 0; j < c->H; ++j) prod[i * c->H + j] = view_cell(c, p, hx, hy, cy, sy, i, j) ? rew[i * c->H + j] : 0.0;
+      const double r = pw_sum(p, prod);
+      if (max_reward < r) {
+        best = a;
+        max_reward = r;
+      }
+    }
+    act[e] = p->yaw_space[best] / p->yaw_rate_max; /* :127 */
+    free(sw);
+  }
+  if (bad) return fail(-4, "gaze: more plan() calls than tobs_tab holds");
+  return 0;
+}
+
+int d2d_oracle_plan_reset(const d2d_cfg *c, const d2d_plan *p, const uint8_t *mask, int32_t mask_stride, void *stream) {
+  (void)stream;
+  if (!c || !p) return fail(-1, "null cfg/plan");
+  size_t N = (size_t)(c->N > 0 ? c->N : 1);
+  for (int e = 0; e < c->B; ++e) {
+    if (mask && !mask[(size_t)e * mask_stride]) continue;
+    if (p->traj_hdr) p->traj_hdr[2 * e] = p->traj_hdr[2 * e + 1] = 0;
+    if (p->trk_radius && p->trk_radius0) memcpy(p->trk_radius + e * N, p->trk_radius0 + e * N, sizeof(double) * N);
+    if (p->trk_prev) memset(p->trk_prev + e * N, 0, N);
+    if (p->seen_step) memset(p->seen_step + (size_t)e * c->W * c->H, 0, sizeof(int32_t) * (size_t)c->W * c->H);
+  }
+  return 0;
+}
+
+int d2d_oracle_closed_loop(const d2d_cfg *c, const d2d_state *s, const d2d_plan *p, int32_t nsteps, int32_t auto_reset,
+                           const d2d_state *init, void *stream) {
+  (void)stream;
+  int rc = plan_check(c, s, p);
+  if (rc) return rc;
+  if (auto_reset && !init) return fail(-1, "closed_loop: auto_reset needs the snapshot");
+  for (int t = 0; t < nsteps; ++t) {
+    if ((rc = d2d_oracle_gaze_stage(c, s, p, 0))) return rc;
+    if ((rc = d2d_oracle_run_stages(c, s, D2D_ST_PERCEIVE, 0))) return rc;
+    if ((rc = d2d_oracle_plan_stage(c, s, p, 0))) return rc;
+    if ((rc = d2d_oracle_run_stages(c, s, D2D_ST_ACT, 0))) return rc;
+    if (auto_reset) { /* the next episode starts from the seeded world with fresh plugin objects (main.py:26-57) */
+      uint8_t *done = (uint8_t *)malloc((size_t)c->B);
+      for (int e = 0; e < c->B; ++e) done[e] = s->flags[(size_t)e * 4 + D2D_F_DONE];
+      rc = d2d_oracle_reset(c, s, init, done, 0);
+      if (!rc) rc = d2d_oracle_plan_reset(c, p, done, 1, 0);
+      free(done);
+      if (rc) return rc;
+    }
+  }
+  return 0;
+}
+
+int d2d_oracle_sincos_array(const double *in, double *so, double *co, int64_t n, void *stream) {
+  (void)stream;
+  for (int64_t i = 0; i < n; ++i) {
+    so[i] = sin(in[i]);
+    co[i] = cos(in[i]);
+  }
   return 0;
 }

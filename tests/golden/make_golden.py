@@ -245,7 +245,29 @@ def gen_flags():
     save('deadlock_primitive', run_trace(p, 14, policy='LookAhead', stop_on_done=False))
 
 
+def gen_closed():
+    """Closed-loop Oxford + Primitive episodes (the planner and the gaze policy are the reference's own objects): pin
+    the device plugins -- action, plan result, head waypoint, trajectory length per step."""
+    cases = {
+        'closed_oxford_n20_map0': dict(agent_number=20, agent_radius=10, agent_max_speed=40, map_id=0),
+        'closed_oxford_n20_map5': dict(agent_number=20, agent_radius=10, agent_max_speed=40, map_id=5),
+        'closed_oxford_pillars_map2': dict(agent_number=8, agent_radius=12, agent_max_speed=20, map_id=2, pillar_number=8),
+        'closed_oxford_pillars_map6': dict(agent_number=15, agent_radius=8, agent_max_speed=30, map_id=6, pillar_number=6),
+        'closed_oxford_slow_drone': dict(agent_number=10, agent_radius=15, agent_max_speed=20, map_id=3, drone_max_speed=30),
+        'closed_oxford_fast_drone': dict(agent_number=10, agent_radius=10, agent_max_speed=20, map_id=4, drone_max_speed=60),
+        'closed_oxford_fov120': dict(agent_number=12, agent_radius=12, agent_max_speed=30, map_id=8, drone_view_range=120,
+                                     drone_view_depth=100),
+        'closed_oxford_two_targets': dict(agent_number=6, agent_radius=10, agent_max_speed=20, map_id=9,
+                                          target_list=[[250, 250], [450, 60]]),
+    }
+    for name, kw in cases.items():
+        p = make_params(gaze_method='Oxford', planner='Primitive', **kw)
+        save(name, run_trace(p, 400, policy='Oxford'))
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == 'closed':
+        return gen_closed()
     if len(sys.argv) > 1 and sys.argv[1] == 'sweep':
         return gen_sweep()
     if len(sys.argv) > 1 and sys.argv[1] == 'rows':
@@ -342,6 +364,7 @@ def main():
     gen_sweep()
     gen_rows()
     gen_flags()
+    gen_closed()
 
 
 if __name__ == '__main__':

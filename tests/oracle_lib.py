@@ -55,6 +55,23 @@ class OracleBackend:
         self._chk(self.fn['reset'](C.byref(cfg), C.byref(st), C.byref(init),
                                    None if mask is None else mask.data_ptr(), None))
 
+    def gaze_stage(self, cfg, st, plan):
+        self._chk(self.fn['gaze_stage'](C.byref(cfg), C.byref(st), C.byref(plan), None))
+
+    def plan_stage(self, cfg, st, plan):
+        self._chk(self.fn['plan_stage'](C.byref(cfg), C.byref(st), C.byref(plan), None))
+
+    def closed_loop(self, cfg, st, plan, nsteps, auto_reset=False, init=None):
+        self._chk(self.fn['closed_loop'](C.byref(cfg), C.byref(st), C.byref(plan), nsteps, 1 if auto_reset else 0,
+                                         None if init is None else C.byref(init), None))
+
+    def plan_reset(self, cfg, plan, mask=None, mask_stride=1):
+        self._chk(self.fn['plan_reset'](C.byref(cfg), C.byref(plan), None if mask is None else mask.data_ptr(),
+                                        mask_stride, None))
+
+    def sincos_array(self, x, s, c):
+        self._chk(self.fn['sincos_array'](x.data_ptr(), s.data_ptr(), c.data_ptr(), x.numel(), None))
+
     def tan_array(self, x, out):
         self._chk(self.fn['tan_array'](x.data_ptr(), out.data_ptr(), x.numel(), None))
 

@@ -36,6 +36,18 @@ def test_header_constants_match_ctypes_mirror(pkg):
             names += [n.strip() for n in m.group(2).split(',')]
     assert names == [f[0] for f in A.Cfg._fields_]
     assert C.sizeof(A.Cfg) == 12 * 4 + 16 * 8 and C.sizeof(A.State) == len(A.STATE_FIELDS) * 8
+    # d2d_plan: scalars in declaration order, then the pointers
+    body = HDR[HDR.index('typedef struct d2d_plan {'):HDR.index('} d2d_plan;')]
+    names = []
+    for line in body.splitlines():
+        line = line.split('/*')[0]
+        m = re.match(r'\s*(?:const\s+)?(int32_t|double|int64_t|uint64_t|uint8_t)\s+\*?\s*(\w+);', line)
+        if m:
+            names.append(m.group(2))
+    assert names == [f[0] for f in A.Plan._fields_]
+    assert C.sizeof(A.Plan) == 14 * 4 + 7 * 8 + 2 * 8 + (len(A.PLAN_TABLES) + len(A.PLAN_STATE)) * 8
+    for name, val in (('D2D_NODE_F', A.NODE_F), ('D2D_PLAN_PRIMITIVE', A.PLAN_PRIMITIVE), ('D2D_GAZE_OXFORD', A.GAZE_OXFORD)):
+        assert int(defs[name]) == val, name
 
 
 def test_hip_library_exports_every_declared_symbol(pkg):
@@ -63,6 +75,8 @@ def test_argument_validation_without_gpu(pkg):
     c.scale = 10.0
     assert fn['step'](C.byref(c), C.byref(s), None) == -1 and b'null' in fn['last_error']()
     assert fn['tan_array'](None, None, 5, None) == -1
+    assert fn['sincos_array'](None, None, None, 5, None) == -1
+    assert fn['plan_stage'](C.byref(c), C.byref(s), None, None) == -1        # null state pointers are refused first
 
 
 def test_oracle_exports_the_same_surface(pkg, oracle):

@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 
 
 def test_native_library_is_loaded(hip):
-    assert hip.fn['abi_version']() == 4
+    assert hip.fn['abi_version']() == 5
     import drone2d_amd
     with open('/proc/self/maps') as f:
         assert 'libd2d_hip.so' in f.read()

@@ -1,0 +1,133 @@
+"""Device planner / gaze plugins on the GPU (run with -m gpu): the HIP kernels against the episodes captured from
+the imported reference, against libm (sin / cos), and against the CPU oracle on seeded batches -- every field of
+the env state AND of the plugin state bit for bit."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+import replay
+from test_gpu_vs_oracle import FIELDS, _worlds
+from test_plugins_cpu import _closed_loop
+from test_sincos import sincos_arguments
+
+pytestmark = pytest.mark.gpu
+
+PLUGIN_FIELDS = ('traj_hdr', 'trk_radius', 'trk_prev', 'seen_step')
+
+
+@pytest.mark.parametrize('name', replay.TRACES_CLOSED + replay.TRACES_PLANNED)
+def test_hip_plugins_reproduce_the_reference_episode(pkg, hip, name):
+    _closed_loop(pkg, hip, name)
+
+
+def test_device_sincos_is_bit_identical_to_libm(hip):
+    rng = np.random.RandomState(6)
+    x = sincos_arguments(rng)
+    xd = torch.from_numpy(x).to(hip.device)
+    sd, cd = torch.empty_like(xd), torch.empty_like(xd)
+    hip.sincos_array(xd, sd, cd)
+    hip.sync()
+    libm = C.CDLL('libm.so.6')
+    idx = np.concatenate([rng.randint(0, x.size, 300000), np.arange(x.size - 12000, x.size)])
+    for name, got in (('sin', sd.cpu().numpy()), ('cos', cd.cpu().numpy())):
+        fn = getattr(libm, name)
+        fn.restype = C.c_double
+        fn.argtypes = [C.c_double]
+        ref = np.array([fn(float(v)) for v in x[idx]])
+        assert np.array_equal(got[idx].view(np.int64), ref.view(np.int64)), name
+
+
+def _pair(pkg, hip, oracle, B, **pk):
+    from drone2d_amd import vec_env
+    p = pkg.Params(planner='Primitive', gaze_method='Oxford', **pk)
+    ref = vec_env.VecDrone2DEnv(p, B, backend=oracle, planner='Primitive', device_plugins=True, gaze='Oxford')
+    dev = vec_env.VecDrone2DEnv(p, B, backend=hip, planner='Primitive', device_plugins=True, gaze='Oxford', worlds=_worlds(ref))
+    return dev, ref
+
+
+def _assert_same(dev, ref, tag):
+    dev.sync()
+    for name in FIELDS + ('action', 'plan_ok', 'wp_valid', 'wp'):
+        a, b = dev.state.t[name].cpu(), ref.state.t[name]
+        if not torch.equal(a, b):
+            bad = (a != b).nonzero()
+            raise AssertionError(f'{tag}: field {name} differs at {bad[:5].tolist()} ({len(bad)} elements)')
+    for name in PLUGIN_FIELDS:
+        a, b = dev.plugins.t[name].cpu(), ref.plugins.t[name]
+        if not torch.equal(a, b):
+            bad = (a != b).nonzero()
+            raise AssertionError(f'{tag}: plugin field {name} differs at {bad[:5].tolist()} ({len(bad)} elements)')
+    # the stored part of every trajectory
+    hd = ref.plugins.t['traj_hdr']
+    ta, tb = dev.plugins.t['traj'].cpu(), ref.plugins.t['traj']
+    for e in range(ref.num_envs):
+        h, n = int(hd[e, 0]), int(hd[e, 1])
+        assert torch.equal(ta[e, h:n], tb[e, h:n]), f'{tag}: trajectory of env {e}'
+    assert int(dev.plugins.t['plan_stat'][:, 3].sum()) == 0
+
+
+CASES = [
+    dict(B=48, T=160, chunk=8, agent_number=10, agent_radius=15, agent_max_speed=20, drone_max_speed=40, map_id=1),
+    dict(B=24, T=90, chunk=5, agent_number=30, agent_radius=10, agent_max_speed=40, map_id=40),
+    dict(B=16, T=120, chunk=6, agent_number=12, agent_radius=10, agent_max_speed=25, map_id=70, pillar_number=7),
+    dict(B=6, T=60, chunk=4, agent_number=10, agent_radius=10, agent_max_speed=20, map_id=4, drone_max_speed=60),
+    dict(B=8, T=70, chunk=7, agent_number=8, agent_radius=12, agent_max_speed=20, map_id=90, drone_max_speed=30,
+         drone_view_range=120, drone_view_depth=100, target_list=[[250, 250], [450, 60]]),
+    dict(B=6, T=40, chunk=5, agent_number=10, agent_radius=10, agent_max_speed=40, map_id=3,
+         static_map='maps/obstacle_map.npy'),
+]
+
+
+@pytest.mark.parametrize('case', CASES, ids=lambda c: f"N{c['agent_number']}_B{c['B']}_v{c.get('drone_max_speed', 40)}")
+def test_closed_loop_matches_oracle(pkg, hip, oracle, case):
+    """gaze -> perceive -> plan -> act with auto reset, `chunk` steps per call, compared after every call."""
+    case = dict(case)
+    B, T, chunk = case.pop('B'), case.pop('T'), case.pop('chunk')
+    dev, ref = _pair(pkg, hip, oracle, B, **case)
+    oracle_threads = getattr(oracle.lib, 'd2d_oracle_set_threads')
+    oracle_threads(8)
+    try:
+        done_seen = 0
+        for t in range(0, T, chunk):
+            dev.closed_loop(chunk, auto_reset=True)
+            ref.closed_loop(chunk, auto_reset=True)
+            _assert_same(dev, ref, f'after step {t + chunk}')
+            done_seen += int((ref.state.counters[:, pkg._abi.C_STEPS] < t + chunk).sum())
+        assert done_seen > 0 or T < 100      # the longer cases do see episodes end and restart
+    finally:
+        oracle_threads(1)
+
+
+def test_full_size_closed_loop_properties(pkg, hip):
+    """BASELINE config 2 with the plugins on the device: 4096 envs, Oxford + Primitive.  Size-independent properties:
+    copies of one world stay identical, actions are yaw-rate candidates, trajectories are consistent."""
+    from drone2d_amd import vec_env, host_init
+    p = pkg.Params(planner='Primitive', gaze_method='Oxford', agent_number=10, agent_radius=15, agent_max_speed=20,
+                   drone_max_speed=40, map_id=1)
+    worlds = [host_init.init_world(_with_map(p, 1 + (i % 64))) for i in range(64)]
+    B = 4096
+    env = vec_env.VecDrone2DEnv(p, B, backend=hip, planner='Primitive', device_plugins=True, gaze='Oxford',
+                                worlds=[worlds[i % 64] for i in range(B)])
+    env.closed_loop(120, auto_reset=True)
+    env.sync()
+    for name in ('drone', 'counters', 'dmap', 'gt', 'kf'):
+        t = env.state.t[name]
+        assert torch.equal(t[:64], t[64:128]) and torch.equal(t[:64], t[B - 64:]), name
+    a = env.state.action.cpu().numpy()
+    cand = np.concatenate([np.arange(-80, 80, 80 / 3) / 80, [0.0]])
+    assert np.isin(a, cand).all()
+    hd = env.plugins.t['traj_hdr'].cpu().numpy()
+    assert (hd[:, 0] <= hd[:, 1]).all() and (hd[:, 1] % 20 == 0).all()
+    assert int(env.plugins.t['plan_stat'][:, 3].sum()) == 0 and int(env.plugins.t['plan_stat'][:, 0].min()) >= 1
+    # README episode (map_id 1) ends at step 210 with the goal reached: env 0 is that world
+    fx = replay.load('readme_oxford_primitive')
+    assert np.array_equal(env.state.drone[0, :3].cpu().numpy(), fx['t_drone'][119])
+
+
+def _with_map(p, map_id):
+    import copy
+    q = copy.copy(p)
+    q.map_id = map_id
+    return q

@@ -1,0 +1,82 @@
+"""csrc/d2d_sincos.h (the sin / cos the Oxford kernel uses) compiled for the host, against the libm the
+reference's math.sin / math.cos resolve to (yaw_planner.py:71): bit for bit.  The device build is checked in
+test_gpu_plugins.py."""
+import ctypes as C
+import math
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def sc_host(tmp_path_factory):
+    so = str(tmp_path_factory.mktemp('sincos') / 'libschost.so')
+    subprocess.check_call(['gcc', '-O2', '-ffp-contract=off', '-mfma', '-fPIC', '-shared',
+                           '-I', os.path.join(ROOT, 'gym-drone2d-activeperception_amd', 'csrc'),
+                           '-o', so, os.path.join(ROOT, 'tests', 'csrc', 'sincos_host.c'), '-lm'])
+    lib = C.CDLL(so)
+    out = {}
+    for name in ('sin', 'cos'):
+        fn = getattr(lib, f'd2d_{name}_host_array')
+        fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+
+        def f(x, fn=fn):
+            x = np.ascontiguousarray(x, dtype=np.float64)
+            o = np.empty_like(x)
+            fn(x.ctypes.data, o.ctypes.data, x.size)
+            return o
+        out[name] = f
+    return out
+
+
+def _cpu_has_fma():
+    try:
+        return ' fma ' in open('/proc/cpuinfo').read()
+    except OSError:
+        return True
+
+
+def sincos_arguments(rng):
+    xs = [rng.uniform(0, 2 * np.pi, 2_000_000), rng.uniform(-60, 60, 500_000), rng.uniform(-0.9, 0.9, 500_000),
+          rng.uniform(-0.13, 0.13, 200_000), rng.uniform(0.8, 2.5, 300_000), rng.uniform(-3e-8, 3e-8, 50_000)]
+    # what the policy actually feeds: radians(yaw) for yaw on the grids the yaw-rate candidates generate
+    yaw = np.concatenate([np.arange(0, 360, 1 / 3.0), (270 + np.arange(-2000, 2000) * (80 / 3) * 0.1) % 360,
+                          (270 + np.arange(0, 400) * 8.0) % 360])
+    xs.append(yaw * (math.pi / 180))
+    for k in range(0, 9):       # neighbourhoods of every multiple of pi/4
+        lo = k * math.pi / 4
+        for _ in range(100):
+            lo = np.nextafter(lo, -np.inf)
+        v = [lo]
+        for _ in range(200):
+            v.append(np.nextafter(v[-1], np.inf))
+        xs.append(np.array(v))
+    b1, b2 = float.fromhex('0x1.b6p-1'), float.fromhex('0x1.368fdp+1')      # range boundaries of the algorithm
+    xs.append(np.array([0.0, -0.0, b1, b2, np.nextafter(b1, 0), np.nextafter(b2, 0)]))
+    return np.concatenate(xs)
+
+
+@pytest.mark.skipif(not _cpu_has_fma(), reason='libm dispatches a non-FMA sin / cos variant on this CPU')
+def test_sincos_restatement_is_bit_identical_to_libm(sc_host):
+    rng = np.random.RandomState(5)
+    x = sincos_arguments(rng)
+    libm = C.CDLL('libm.so.6')
+    idx = np.concatenate([rng.randint(0, x.size, 250000), np.arange(x.size - 12000, x.size)])
+    for name in ('sin', 'cos'):
+        got = sc_host[name](x)
+        fn = getattr(libm, name)
+        fn.restype = C.c_double
+        fn.argtypes = [C.c_double]
+        ref = np.array([fn(float(v)) for v in x[idx]])
+        assert np.array_equal(got[idx].view(np.int64), ref.view(np.int64)), name
+        m = np.array([getattr(math, name)(float(v)) for v in x[:50000]])      # and Python's math module itself
+        assert np.array_equal(got[:50000].view(np.int64), m.view(np.int64)), name
+
+
+def test_radians_constant():
+    assert (math.pi / 180).hex() == '0x1.1df46a2529d39p-6'
+    assert all(math.radians(y) == y * (math.pi / 180) for y in (0.0, 45.0, 270.0, 123.456, 359.99999))
