@@ -1,20 +1,23 @@
 #!/usr/bin/env python3
-"""bench.py — env-steps/s of the batched Drone2D step on MI355X (BASELINE.json metric).
+"""bench.py — env-steps/s of the batched Drone2D environment on MI355X (BASELINE.json metric).
 
-  python bench.py --gpus 1 --steps 200 --warmup 20
+  python bench.py --gpus 1 --steps 600 --warmup 100
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W
 
-Workload (N=1): BASELINE.json configs[1] — 4096 batched envs x 10 agents, agent_radius=15, 50x50 grid,
-50 rays, env i = the reference world for map_id 1+i.  A "step" = one fused Drone2DEnv2.step over the
-whole batch (d2d_step launches: by default the batch is cut into 2 independent halves stepped on two
-free-running HIP streams, envs being independent; --streams 1 = one launch per step).  Gaze actions are fixed-seed U(-1,1) and the planner result is a
-synthetic resident waypoint stream (the device follows it exactly as it follows a Primitive trajectory
-head; Oxford/Primitive themselves are host plugins in the reference and not part of this hot path —
-SURVEY.md 8(d) C2).  Inputs are resident in HBM before the timed region.  N>1: every rank steps its own
-shard of 4096 envs (weak scaling, no per-step collective; one RCCL all_gather of episode statistics).
+Workload (N=1): BASELINE.json configs[1] — 4096 batched envs x 10 agents, agent_radius=15, 50x50 grid, 50 rays,
+Oxford gaze, Primitive planner; env i = the reference world for map_id 1+i.  A "step" = one reference-style step
+of every env: a = Oxford.plan(info); Drone2DEnv2.step(a) with Primitive.replan_check / plan in the middle
+(experiment.py:68-70), ALL of it on the device (d2d_closed_loop: one persistent launch, every wave loops over the
+steps of its own env), finished episodes restarting from their seeded world (main.py:26-57).  Nothing is replayed
+or skipped inside the timed region.  State is resident in HBM before the timed region.
 
-Prints ONE JSON line on rank 0.
+Besides the headline the line carries `step_kernel`: the fused Drone2DEnv2.step kernel alone (k_stages; gaze
+actions and planner heads resident in HBM, SURVEY.md 8(d) C2's replay mode), timed with HIP events after the
+timed region -- the HBM-roofline figure of the raycast / step kernel the north star asks for.
+
+N>1: every rank runs its own shard of 4096 envs (weak scaling, no per-step collective; one RCCL all_gather of
+episode statistics).  Prints ONE JSON line on rank 0.
 """
 import argparse
 import ctypes as C
@@ -60,70 +63,110 @@ def host_cores():
     return n
 
 
-def cpu_baseline(pkg, params, budget_s=14.0):
-    """The CPU oracle (oracle/, a scalar C port of the reference step) timed on this box's host cores on a
-    bounded sample of the same workload: 2048 envs of the same family, NoMove, same kind of action stream.
-    Timed on 1 thread and on min(cores, 32) OpenMP threads over envs; the faster is reported with the thread
-    count actually used."""
+def cpu_baseline(pkg, params, budget_s=16.0):
+    """The CPU oracle (oracle/, a scalar C port of the reference: step + Oxford + Primitive) timed on this box's
+    host cores on a bounded sample of the same workload: the same closed loop (gaze -> perceive -> plan -> act,
+    auto reset) over 512 envs of the same family.  Timed on 1 thread and on min(cores, 32) OpenMP threads over
+    envs; the faster is reported with the thread count actually used."""
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
-    import numpy as np
     from oracle_lib import OracleBackend
     from drone2d_amd import vec_env
     ob = OracleBackend()
     avail = host_cores()
     many = max(1, min(avail, 32))
-    B = 2048
+    B = 512
     worlds = vec_env.build_worlds(params, 64, workers=0)
-    env = vec_env.VecDrone2DEnv(params, B, backend=ob, planner='NoMove', worlds=[worlds[i % 64] for i in range(B)])
-    rng = np.random.RandomState(0)
     out = {}
     for threads in sorted({1, many}):
+        env = vec_env.VecDrone2DEnv(params, B, backend=ob, planner='Primitive', device_plugins=True, gaze='Oxford',
+                                    worlds=[worlds[i % 64] for i in range(B)])
         ob.lib.d2d_oracle_set_threads(threads)
-        env.reset()
         n = 0
         t0 = time.perf_counter()
         while time.perf_counter() - t0 < budget_s / 2:
-            env.step(rng.uniform(-1, 1, B))
-            n += 1
+            env.closed_loop(2, auto_reset=True)
+            n += 2
         out[threads] = B * n / (time.perf_counter() - t0)
     ob.lib.d2d_oracle_set_threads(1)
     best = max(out, key=out.get)
     return {'value': out[best], 'unit': 'env-steps/s', 'cores': best, 'kind': 'port',
             'single_core_value': out[1], 'host_cores_available': avail,
-            'sample': f'oracle/d2d_oracle.c, {B} envs x 10 agents (64 distinct seeded worlds of the GPU workload\'s '
-                      f'family, NoMove), ~{budget_s / 2:.0f} s per thread count {sorted(out)}; '
-                      'reference Python itself: 268 env-steps/s on 1 core (BASELINE.md, build container)'}
+            'sample': f'oracle/d2d_oracle.c closed loop (Oxford + Primitive + step, auto reset), {B} envs x 10 agents (64 '
+                      f'distinct seeded worlds of the GPU workload\'s family), ~{budget_s / 2:.0f} s per thread count '
+                      f'{sorted(out)}; reference Python itself: 16.3 env-steps/s for this loop on 1 core (BASELINE.md, '
+                      'build container)'}
+
+
+def step_kernel_leg(torch, env, params, rank, device, B, K=500, Wm=50):
+    """The fused Drone2DEnv2.step kernel alone: K d2d_step launches over the batch (one launch = B envs), gaze
+    actions and planner heads resident in HBM, timed with HIP events on the launch stream."""
+    T = K + Wm
+    g = torch.Generator().manual_seed(1234 + rank)
+    actions = (torch.rand(T, B, generator=g, dtype=torch.float64) * 2 - 1).to(device)
+    wp = synth_plan(torch, T, B, params.map_size[0], params.map_size[1], 99 + rank, device)
+    env.state.plan_ok.fill_(1)
+    env.state.wp_valid.fill_(1)
+    be = env.backend
+    st = env.state.struct()
+    stream = torch.cuda.current_stream(device)
+    sp = C.c_void_p(stream.cuda_stream)
+
+    def roll(t0, n):
+        rc = be.fn['rollout'](C.byref(env.cfg), C.byref(st), n, actions.data_ptr() + t0 * B * 8, wp.data_ptr() + t0 * B * 48,
+                              None, None, sp)
+        if rc:
+            raise RuntimeError(be.fn['last_error']().decode())
+    roll(0, Wm)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    roll(Wm, K)
+    e1.record(stream)
+    torch.cuda.synchronize()
+    launch_us = e0.elapsed_time(e1) * 1e3 / K
+    achieved = ALGO_BYTES_PER_ENV_STEP * B / (launch_us * 1e-6) / 1e9
+    return {'kernel': 'k_stages (fused Drone2DEnv2.step: agents, raycast, dynamic grid, trackers, control, collision, obs)',
+            'inputs': 'fixed-seed U(-1,1) gaze actions and synthetic waypoint heads resident in HBM (replay mode)',
+            'launches': K, 'envs_per_launch': B, 'launch_us': launch_us, 'env_steps_per_s': B / (launch_us * 1e-6),
+            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': _pmc('step_kernel_hbm_bytes_per_launch'),
+                         'algo_bytes_per_env_step': ALGO_BYTES_PER_ENV_STEP}}
+
+
+def _pmc(key):
+    pj = os.path.join(ROOT, 'profiles', 'pmc_latest.json')
+    try:
+        return json.load(open(pj)).get(key)
+    except Exception:
+        return None
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=500)
-    ap.add_argument('--warmup', type=int, default=50)
+    ap.add_argument('--steps', type=int, default=600)
+    ap.add_argument('--warmup', type=int, default=100)
     ap.add_argument('--envs', type=int, default=4096, help='envs per GPU')
     ap.add_argument('--agents', type=int, default=10)
     ap.add_argument('--static-map', default='maps/empty_map.npy', help='exploration only: other BASELINE configs')
     ap.add_argument('--agent-speed', type=int, default=20)
     ap.add_argument('--agent-radius', type=int, default=15)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-step-kernel', action='store_true', help='skip the step-kernel-only leg after the timed region')
     ap.add_argument('--workers', type=int, default=min(8, os.cpu_count() or 1),
                     help='host processes building the worlds (forked BEFORE the GPU is touched; 0 = in-process, '
                          'use 0 under rocprofv3)')
     ap.add_argument('--dist-backend', default='nccl', choices=['nccl', 'gloo'],
                     help='gloo + --single-device: dry run of the multi-rank path on a 1-GPU box')
     ap.add_argument('--single-device', action='store_true', help='every rank uses cuda:0 (dry run only)')
-    ap.add_argument('--streams', type=int, default=2,
-                    help='>1: the batch is cut into that many sub-batches stepped on free-running HIP streams (envs are '
-                         'independent); the roofline object then describes one sub-batch launch')
-    ap.add_argument('--chunk', type=int, default=10, help='chain mode: steps queued per d2d_rollout call')
-    ap.add_argument('--mode', default='chain', choices=['chain', 'launch', 'graph'],
-                    help='chain: the K steps of a stream are queued by ONE d2d_rollout call (default); launch: one '
-                         'd2d_step call per step from Python; graph: the K launches captured in one hipGraph')
+    ap.add_argument('--chunk', type=int, default=300, help='steps per persistent d2d_closed_loop launch')
+    ap.add_argument('--no-persistent', action='store_true',
+                    help='exploration: one launch per stage per step (gaze, perceive, plan, act) instead of the persistent kernel')
     args = ap.parse_args()
 
     import torch
     import drone2d_amd as pkg
-    from drone2d_amd import vec_env, _abi as A
+    from drone2d_amd import vec_env
 
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -147,97 +190,36 @@ def main():
     torch.cuda.set_device(local)
     coll_dev = device if args.dist_backend == 'nccl' else 'cpu'
 
-    env = vec_env.VecDrone2DEnv(params, B, device=device, planner='external', env_offset=rank * B, worlds=worlds)
-    T = K + Wm
-    g = torch.Generator().manual_seed(1234 + rank)
-    actions = (torch.rand(T, B, generator=g, dtype=torch.float64) * 2 - 1).to(device)
-    wp = synth_plan(torch, T, B, params.map_size[0], params.map_size[1], 99 + rank, device)
-    env.state.plan_ok.fill_(1)
-    env.state.wp_valid.fill_(1)
-    be = env.backend
-    fn_step = be.fn['step']
-    a_ptr, w_ptr = actions.data_ptr(), wp.data_ptr()
-    S = max(1, min(args.streams, B))
-    import copy
-    main_stream = torch.cuda.current_stream(device)
-    base = env.state.struct()
-    subs = []
-    for i in range(S):
-        lo, hi = (B * i) // S, (B * (i + 1)) // S
-        cfg_i = copy.copy(env.cfg)
-        cfg_i.B = hi - lo
-        st_i = A.State()
-        for name in A.STATE_FIELDS:
-            t = env.state.t.get(name)
-            ptr = getattr(base, name)
-            setattr(st_i, name, None if (t is None or not ptr) else ptr + lo * t.stride(0) * t.element_size())
-        stream_i = main_stream if S == 1 else torch.cuda.Stream(device)
-        subs.append((lo, cfg_i, st_i, stream_i, C.c_void_p(stream_i.cuda_stream)))
-    # chain mode: each sub-batch owns contiguous [T][b] actions and [T][b][6] planner heads
-    chain_in = [(actions[:, lo:lo + c_.B].contiguous(), wp[:, lo:lo + c_.B].contiguous()) for lo, c_, _, _, _ in subs]
-    fn_roll = be.fn['rollout']
+    env = vec_env.VecDrone2DEnv(params, B, device=device, planner='Primitive', env_offset=rank * B, worlds=worlds,
+                                device_plugins=True, gaze='Oxford')
+    if args.no_persistent:
+        env._plan.launch_args = None
+    stream = torch.cuda.current_stream(device)
 
-    def chain(t0, n, chunk=10):
-        # the chains are fed round-robin in chunks of `chunk` steps so that the streams stay abreast of each other
-        for c0 in range(t0, t0 + n, chunk):
-            m = min(chunk, t0 + n - c0)
-            for (lo, cfg_i, st_i, _, sp_i), (a_i, w_i) in zip(subs, chain_in):
-                b = cfg_i.B
-                rc = fn_roll(C.byref(cfg_i), C.byref(st_i), m, a_i.data_ptr() + c0 * b * 8,
-                             w_i.data_ptr() + c0 * b * 48, None, None, sp_i)
-                if rc:
-                    raise RuntimeError(be.fn['last_error']().decode())
+    def run(n):
+        for c0 in range(0, n, args.chunk):
+            env.closed_loop(min(args.chunk, n - c0), auto_reset=True)
 
-    def launch(t):
-        for lo, cfg_i, st_i, _, sp_i in subs:
-            st_i.action = a_ptr + (t * B + lo) * 8
-            st_i.wp = w_ptr + (t * B + lo) * 6 * 8
-            rc = fn_step(C.byref(cfg_i), C.byref(st_i), sp_i)
-            if rc:
-                raise RuntimeError(be.fn['last_error']().decode())
-
-    if args.mode == 'chain':
-        chain(0, Wm)
-    else:
-        for t in range(Wm):
-            launch(t)
+    run(Wm)
     torch.cuda.synchronize()
-
-    graph = None
-    if args.mode == 'graph':
-        assert S == 1, '--mode graph needs --streams 1'
-        graph = torch.cuda.CUDAGraph()
-        cs = torch.cuda.Stream(device)
-        with torch.cuda.graph(graph, stream=cs):
-            subs[0] = subs[0][:4] + (C.c_void_p(torch.cuda.current_stream(device).cuda_stream),)
-            for t in range(Wm, T):
-                launch(t)
-        torch.cuda.synchronize()
-
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in subs]
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
-    for (e0, _), sub in zip(ev, subs):
-        e0.record(sub[3])
-    if graph is not None:
-        graph.replay()
-    elif args.mode == 'chain':
-        chain(Wm, K, args.chunk)
-    else:
-        for t in range(Wm, T):
-            launch(t)
-    for (_, e1), sub in zip(ev, subs):
-        e1.record(sub[3])
+    e0.record(stream)
+    run(K)
+    e1.record(stream)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    gpu_ms = sum(e0.elapsed_time(e1) for e0, e1 in ev) / len(ev)      # HIP-event time of the K launches of a stream
+    gpu_ms = e0.elapsed_time(e1)                  # HIP-event time of the K steps on the launch stream
+    nlaunch = (K + args.chunk - 1) // args.chunk
 
     # episode statistics: the only exchange of the path (RCCL all_gather over xGMI), once per run
     stats = env.episode_stats()
+    pstat = env.plugins.t['plan_stat'].long()
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -249,38 +231,41 @@ def main():
 
     if rank == 0:
         value = world * B * K / elapsed
-        launch_us = gpu_ms * 1e3 / K                       # HIP-event time per launch on the launch stream
-        achieved = ALGO_BYTES_PER_ENV_STEP * (B / S) / (launch_us * 1e-6) / 1e9   # bytes of ONE launch / its duration
-        traffic = None
-        pj = os.path.join(ROOT, 'profiles', 'pmc_latest.json')
-        if os.path.isfile(pj):
-            try:
-                traffic = json.load(open(pj)).get('hbm_bytes_per_launch')
-            except Exception:
-                traffic = None
+        launch_us = gpu_ms * 1e3 / nlaunch              # one persistent launch = `chunk` steps of every env
+        steps_per_launch = K / nlaunch
+        achieved = ALGO_BYTES_PER_ENV_STEP * B * steps_per_launch / (launch_us * 1e-6) / 1e9
         line = {
             'metric': 'env-steps/sec (batched) at 10 agents, map_id=1', 'value': value, 'unit': 'env-steps/s',
             'n_gpus': world, 'steps': K, 'warmup': Wm, 'ms_per_step': elapsed * 1e3 / K,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': f'configs[1]: {B} batched envs per GPU x {args.agents} agents, agent_radius=15, '
-                                   '50x50 uint8 grid, 50 rays, map_id=1+env',
-                       'envs_per_gpu': B, 'agents': env.N, 'launch_mode': args.mode, 'streams': S,
-                       'gaze': 'fixed-seed U(-1,1) actions resident in HBM (Oxford is a host plugin)',
-                       'planner': 'synthetic resident waypoint heads, followed as Primitive heads are '
-                                  '(Primitive is a host plugin)',
-                       'kalman_trackers': 'on device', 'auto_reset': False},
+                                   '50x50 uint8 grid, 50 rays, map_id=1+env, Oxford gaze + Primitive planner',
+                       'envs_per_gpu': B, 'agents': env.N,
+                       'gaze': 'Oxford on the device (yaw_planner.py:41-127), every step',
+                       'planner': 'Primitive on the device (traj_planner.py:78-233): replan_check every step, A* search '
+                                  'whenever the trajectory is empty',
+                       'kalman_trackers': 'on device', 'auto_reset': True,
+                       'launch_mode': ('one launch per stage per step' if args.no_persistent else
+                                       f'persistent: one launch per {args.chunk} steps, each wave loops over its own env'),
+                       'searches_per_env': float(pstat[:, 0].double().mean()), 'search_overflows': int(pstat[:, 3].sum())},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'kernel': 'k_stages (fused step)',
-                         'launch_us': launch_us, 'envs_per_launch': B // S, 'concurrent_launches': S,
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': _pmc('hbm_bytes_per_launch'),
+                         'kernel': 'k_closed (persistent closed loop: Oxford + Drone2DEnv2.step + Primitive)',
+                         'launch_us': launch_us, 'envs_per_launch': B, 'steps_per_launch': steps_per_launch,
                          'algo_bytes_per_env_step': ALGO_BYTES_PER_ENV_STEP,
-                         'aggregate_GBs': ALGO_BYTES_PER_ENV_STEP * B * K / elapsed / 1e9},
-            'episode_stats': {'envs': int(stats.shape[0]), 'dynamic_collisions': int(stats[:, 3].sum()),
+                         'note': 'algorithmic bytes of the Drone2DEnv2.step stages (SURVEY 8(d)) x envs x steps of one launch; '
+                                 'the plugin phases are latency / issue bound, `step_kernel` is the step kernel alone'},
+            'episode_stats': {'envs': int(stats.shape[0]), 'running_dynamic_collisions': int(stats[:, 3].sum()),
                               'mean_cells_discovered': float(stats[:, 6].double().mean())},
         }
+        if not args.no_step_kernel:       # after the timed region, on its own state
+            env_hot = vec_env.VecDrone2DEnv(params, B, device=device, planner='external', env_offset=rank * B, worlds=worlds)
+            line['step_kernel'] = step_kernel_leg(torch, env_hot, params, rank, device, B)
         if not args.no_cpu_baseline and world == 1:
             line['cpu_baseline'] = cpu_baseline(pkg, params)
         print(json.dumps(line), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

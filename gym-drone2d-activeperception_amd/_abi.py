@@ -48,7 +48,8 @@ PLAN_INT_FIELDS = ('planner', 'gaze', 'nu', 'n_sample', 'n_ts', 'max_itr', 'traj
                    'pw_nleaf', 'pw_nprog', 'tobs_len', 'reserved')
 PLAN_F64_FIELDS = ('horizon', 'vmax', 'safe_dist', 'goal_tol', 'agent_radius', 'half_fov', 'yaw_rate_max')
 PLAN_TABLES = ('u_space', 'sample_t', 'traj_t', 'yaw_space', 'tobs_tab', 'pw_leaf', 'pw_prog', 'trk_radius0')
-PLAN_STATE = ('traj', 'traj_hdr', 'trk_radius', 'trk_prev', 'seen_step', 'nodes', 'hash', 'plan_stat')
+PLAN_STATE = ('traj', 'traj_hdr', 'trk_radius', 'trk_prev', 'seen_step', 'nodes', 'hash', 'launch_args', 'plan_stat')
+LAUNCH_ARGS_BYTES = 2048
 
 
 class Plan(C.Structure):

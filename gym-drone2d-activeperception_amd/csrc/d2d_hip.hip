@@ -1235,13 +1235,8 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK, D2D_MIN_WAVES) void k_stages
   D2D_STAMP(13);
 }
 
-// reset(): masked copy of the snapshot over the live state, one wave per env
-__global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK) void k_reset(d2d_cfg c, d2d_state s, d2d_state init,
-                                                                 const unsigned char *mask, int mask_stride) {
-  const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
-  const int e = blockIdx.x * WAVES_PER_BLOCK + wv;
-  if (e >= c.B) return;
-  if (mask && !mask[(size_t)e * mask_stride]) return;
+// reset(): copy of the snapshot over the live state of env e by one wave
+__device__ __forceinline__ void reset_env(const d2d_cfg &c, const d2d_state &s, const d2d_state &init, size_t e, int lane) {
   const size_t N = c.N, WH = (size_t)c.W * c.H, LL = (size_t)c.L * c.L;
   for (size_t i = lane; i < D2D_AF * N; i += WAVE) s.agents[e * D2D_AF * N + i] = init.agents[e * D2D_AF * N + i];
   for (size_t i = lane; i < N; i += WAVE) {
@@ -1268,14 +1263,24 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK) void k_reset(d2d_cfg c, d2d_
   }
   for (size_t i = lane; i < LL; i += WAVE) s.obs_local[e * LL + i] = 0;
   for (size_t i = lane; i < (size_t)c.T * 2; i += WAVE) s.targets[e * c.T * 2 + i] = init.targets[e * c.T * 2 + i];
-  if (lane < D2D_DF) s.drone[(size_t)e * D2D_DF + lane] = init.drone[(size_t)e * D2D_DF + lane];
-  if (lane < D2D_CF) s.counters[(size_t)e * D2D_CF + lane] = init.counters[(size_t)e * D2D_CF + lane];
-  if (lane < 2) s.target[(size_t)e * 2 + lane] = init.target[(size_t)e * 2 + lane];
-  if (lane < 4) s.flags[(size_t)e * 4 + lane] = 0;
+  if (lane < D2D_DF) s.drone[e * D2D_DF + lane] = init.drone[e * D2D_DF + lane];
+  if (lane < D2D_CF) s.counters[e * D2D_CF + lane] = init.counters[e * D2D_CF + lane];
+  if (lane < 2) s.target[e * 2 + lane] = init.target[e * 2 + lane];
+  if (lane < 4) s.flags[e * 4 + lane] = 0;
   if (lane == 0) {
     s.newly[e] = 0;
     s.obs_yaw[e] = 0.f;
   }
+}
+
+// masked reset, one wave per env
+__global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK) void k_reset(d2d_cfg c, d2d_state s, d2d_state init,
+                                                                 const unsigned char *mask, int mask_stride) {
+  const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
+  const int e = blockIdx.x * WAVES_PER_BLOCK + wv;
+  if (e >= c.B) return;
+  if (mask && !mask[(size_t)e * mask_stride]) return;
+  reset_env(c, s, init, (size_t)e, lane);
 }
 
 __global__ void k_tan(const double *in, double *out, long long n) {
@@ -1284,6 +1289,114 @@ __global__ void k_tan(const double *in, double *out, long long n) {
 }
 
 #include "d2d_plugins.h"
+
+// ------------------------------------------------------------------------------------------------
+// The closed loop as ONE persistent launch: every wave runs `nsteps` reference-style steps of its own env,
+//   [reset if the previous step ended the episode] -> Oxford.plan -> perceive -> Primitive.replan_check / plan -> act,
+// with only wave-local fences between the phases.  Envs are independent, so nothing has to wait at a kernel
+// boundary for the slowest env of the batch: a 99-expansion search (up to ~1 ms) costs that env's wave its own
+// time instead of stalling 4095 others every step, and a step costs no launches at all.
+// Only for the specialised default geometry (SPEC 1 / 2); other configurations take the launch-per-stage path.
+// ------------------------------------------------------------------------------------------------
+// The launch arguments (four structs of pointers) are parked once in device memory (d2d_plan.launch_args) and every
+// phase is a NON-INLINED function that reads what it needs through scalar loads: inlined into one loop body the
+// by-value arguments all stay live across the loop (474 SGPR + 419 VGPR spills, measured); as calls each phase
+// gets the register allocation it has as a kernel of its own.
+struct ClosedArgs {
+  d2d_cfg c;
+  d2d_state s;
+  d2d_plan p;
+  d2d_state init;
+  int auto_reset, nsteps;
+};
+
+__global__ void k_closed_args(ClosedArgs *dst, d2d_cfg c, d2d_state s, d2d_plan p, d2d_state init, int auto_reset, int nsteps) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    dst->c = c;
+    dst->s = s;
+    dst->p = p;
+    dst->init = init;
+    dst->auto_reset = auto_reset;
+    dst->nsteps = nsteps;
+  }
+}
+
+template <int SPEC>
+__host__ __device__ inline int closed_wave_bytes(const d2d_cfg &c, const d2d_plan &p) {
+  int b = make_geom(c, WAVES_PER_BLOCK, spec_ncap(SPEC)).wave_bytes;
+  const int pb = plan_wave_bytes(c.N), gb = p.gaze == D2D_GAZE_OXFORD ? gaze_geom(c, p).wave_bytes : 0;
+  b = b > pb ? b : pb;
+  b = b > gb ? b : gb;
+  return (b + 15) & ~15;
+}
+
+// function arguments arrive in VGPRs; these are wave-uniform by construction, say so
+__device__ __forceinline__ const ClosedArgs *uniform_ptr(const ClosedArgs *p) {
+  const unsigned long long v = (unsigned long long)p;
+  const unsigned int lo = __builtin_amdgcn_readfirstlane((unsigned int)v), hi = __builtin_amdgcn_readfirstlane((unsigned int)(v >> 32));
+  return (const ClosedArgs *)(((unsigned long long)hi << 32) | lo);
+}
+
+template <int SPEC>
+__device__ __attribute__((noinline)) void ph_gaze(const ClosedArgs *ap, int e_, int lds_off_) {
+  const ClosedArgs *__restrict__ a = uniform_ptr(ap);
+  const int e = __builtin_amdgcn_readfirstlane(e_), lane = threadIdx.x & (WAVE - 1);
+  char *base = d2d_lds + __builtin_amdgcn_readfirstlane(lds_off_);
+  d2d_cfg c = a->c;
+  spec_default_apply(c);
+  gaze_env(c, a->s, a->p, a->init, a->auto_reset, e, lane, base);
+  wave_sync_global();
+}
+
+template <int SPEC>
+__device__ __attribute__((noinline)) void ph_plan(const ClosedArgs *ap, int e_, int lds_off_) {
+  const ClosedArgs *__restrict__ a = uniform_ptr(ap);
+  const int e = __builtin_amdgcn_readfirstlane(e_), lane = threadIdx.x & (WAVE - 1);
+  char *base = d2d_lds + __builtin_amdgcn_readfirstlane(lds_off_);
+  d2d_cfg c = a->c;
+  spec_default_apply(c);
+  plan_env(c, a->s, a->p, e, lane, base);
+  wave_sync_global();
+}
+
+template <int SPEC, uint32_t STAGES>
+__device__ __attribute__((noinline)) void ph_stages(const ClosedArgs *ap, int e_, int lds_off_) {
+  const ClosedArgs *__restrict__ a = uniform_ptr(ap);
+  const int e = __builtin_amdgcn_readfirstlane(e_), lane = threadIdx.x & (WAVE - 1);
+  char *base = d2d_lds + __builtin_amdgcn_readfirstlane(lds_off_);
+  d2d_cfg c = a->c;
+  spec_default_apply(c);
+  const Geom g = make_geom(c, WAVES_PER_BLOCK, spec_ncap(SPEC));
+  const LdsView L = carve(base, g, c.L);
+  EnvRegs r;
+  load_regs(a->s, e, r);
+  run_env(c, a->s, e, lane, STAGES, g, L, a->s.action[e], r);
+  if (lane == 0) store_regs(a->s, e, r);
+  wave_sync_global();
+}
+
+template <int SPEC>
+__global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK, D2D_MIN_WAVES) void k_closed(const ClosedArgs *__restrict__ a) {
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);
+  const int e = blockIdx.x * WAVES_PER_BLOCK + wv;
+  if (e >= a->c.B) return;
+  d2d_cfg c = a->c;
+  spec_default_apply(c);
+  const int off = wv * closed_wave_bytes<SPEC>(c, a->p);
+  const bool split = a->p.planner == D2D_PLAN_PRIMITIVE;
+  const int nsteps = a->nsteps;
+#pragma unroll 1
+  for (int t = 0; t < nsteps; ++t) {
+    ph_gaze<SPEC>(a, e, off);
+    if (split) {
+      ph_stages<SPEC, D2D_ST_PERCEIVE>(a, e, off);
+      ph_plan<SPEC>(a, e, off);
+      ph_stages<SPEC, D2D_ST_ACT>(a, e, off);
+    } else {
+      ph_stages<SPEC, D2D_ST_ALL>(a, e, off);
+    }
+  }
+}
 
 // ------------------------------------------------------------------------------------------------
 // host side of the C ABI
@@ -1402,11 +1515,12 @@ int plan_check(const d2d_cfg *c, const d2d_state *s, const d2d_plan *p) {
   return 0;
 }
 
-int gaze_launch(const d2d_cfg *c, const d2d_state *s, const d2d_plan *p, void *stream) {
-  if (p->gaze != D2D_GAZE_OXFORD || c->B == 0) return 0;
+// `init` != NULL: envs whose flags say "done" are first put back to the snapshot, plugin state included
+int gaze_launch(const d2d_cfg *c, const d2d_state *s, const d2d_plan *p, const d2d_state *init, void *stream) {
+  if ((p->gaze != D2D_GAZE_OXFORD && !init) || c->B == 0) return 0;
   const dim3 grid((c->B + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK), block(WAVE * WAVES_PER_BLOCK);
-  const size_t lds = (size_t)gaze_geom(*c, *p).wave_bytes * WAVES_PER_BLOCK;
-  hipLaunchKernelGGL(k_gaze, grid, block, lds, (hipStream_t)stream, *c, *s, *p);
+  const size_t lds = p->gaze == D2D_GAZE_OXFORD ? (size_t)gaze_geom(*c, *p).wave_bytes * WAVES_PER_BLOCK : 0;
+  hipLaunchKernelGGL(k_gaze, grid, block, lds, (hipStream_t)stream, *c, *s, *p, init ? *init : *s, init ? 1 : 0);
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return fail(-3, hipGetErrorString(err));
   return 0;
@@ -1477,7 +1591,7 @@ int d2d_reset(const d2d_cfg *c, const d2d_state *s, const d2d_state *init, const
 int d2d_gaze_stage(const d2d_cfg *c, const d2d_state *s, const d2d_plan *p, void *stream) {
   int rc = plan_check(c, s, p);
   if (rc) return rc;
-  return gaze_launch(c, s, p, stream);
+  return gaze_launch(c, s, p, nullptr, stream);
 }
 
 int d2d_plan_stage(const d2d_cfg *c, const d2d_state *s, const d2d_plan *p, void *stream) {
@@ -1494,25 +1608,43 @@ int d2d_plan_reset(const d2d_cfg *c, const d2d_plan *p, const uint8_t *mask, int
 
 int d2d_closed_loop(const d2d_cfg *c, const d2d_state *s, const d2d_plan *p, int32_t nsteps, int32_t auto_reset,
                     const d2d_state *init, void *stream) {
-  // gaze -> perceive -> plan -> act per step, all queued on the stream (experiment.py:68-70)
+  // [reset of the envs whose previous step ended the episode +] gaze -> perceive -> plan -> act per step, all
+  // queued on the stream (experiment.py:68-70): 4 launches per step, 2 when the planner stage is not on the device
   int rc = plan_check(c, s, p);
   if (rc) return rc;
   if (nsteps < 0) return fail(-1, "closed_loop: bad step count");
-  if (auto_reset && !init) return fail(-1, "closed_loop: auto_reset needs the snapshot");
+  if (auto_reset && (!init || !init->agents || !init->agent_unit || !init->dyn_prev || !init->gt || !init->dmap ||
+                     !init->drone || !init->target || !init->targets || !init->counters || !init->active))
+    return fail(-1, "closed_loop: auto_reset needs the snapshot");
+  if (c->B == 0 || nsteps == 0) return 0;
+#ifndef D2D_NO_PERSISTENT
+  if (spec_default_matches(*c) && c->N <= spec_ncap(2) && c->planner_mode == D2D_PLANNER_EXTERNAL &&
+      (p->planner == D2D_PLAN_PRIMITIVE || p->gaze == D2D_GAZE_OXFORD)) {
+    // one persistent launch: every wave loops over the steps of its own env
+    const int spec = c->N <= spec_ncap(1) ? 1 : 2;
+    const dim3 grid((c->B + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK), block(WAVE * WAVES_PER_BLOCK);
+    const size_t lds = (size_t)(spec == 1 ? closed_wave_bytes<1>(*c, *p) : closed_wave_bytes<2>(*c, *p)) * WAVES_PER_BLOCK;
+    if (lds <= 64 * 1024 && p->launch_args) {
+      ClosedArgs *dev = (ClosedArgs *)p->launch_args;
+      hipLaunchKernelGGL(k_closed_args, dim3(1), dim3(64), 0, (hipStream_t)stream, dev, *c, *s, *p, auto_reset ? *init : *s,
+                         auto_reset ? 1 : 0, (int)nsteps);
+      if (spec == 1) hipLaunchKernelGGL(k_closed<1>, grid, block, lds, (hipStream_t)stream, (const ClosedArgs *)dev);
+      else hipLaunchKernelGGL(k_closed<2>, grid, block, lds, (hipStream_t)stream, (const ClosedArgs *)dev);
+      hipError_t err = hipGetLastError();
+      if (err != hipSuccess) return fail(-3, hipGetErrorString(err));
+      return 0;
+    }
+  }
+#endif
   const bool split = p->planner == D2D_PLAN_PRIMITIVE;
   for (int32_t t = 0; t < nsteps; ++t) {
-    if ((rc = gaze_launch(c, s, p, stream))) return rc;
+    if ((rc = gaze_launch(c, s, p, auto_reset ? init : nullptr, stream))) return rc;
     if (split) {
       if ((rc = launch_stages(c, s, D2D_ST_PERCEIVE, stream))) return rc;
       if ((rc = plan_launch(c, s, p, stream))) return rc;
       if ((rc = launch_stages(c, s, D2D_ST_ACT, stream))) return rc;
     } else if ((rc = launch_stages(c, s, D2D_ST_ALL, stream))) {
       return rc;
-    }
-    if (auto_reset) {  // the next episode starts from the seeded world with fresh plugin objects (main.py:26-57)
-      // plugin state first: the state reset clears the flags both use as their mask
-      if ((rc = plan_reset_launch(c, p, s->flags + D2D_F_DONE, 4, stream))) return rc;
-      if ((rc = reset_launch(c, s, init, s->flags + D2D_F_DONE, 4, stream))) return rc;
     }
   }
   return 0;

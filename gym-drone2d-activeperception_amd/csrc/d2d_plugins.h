@@ -307,7 +307,6 @@ __device__ int plan_search(const d2d_cfg &c, const d2d_state &s, const d2d_plan 
   return total;
 }
 
-extern __shared__ __attribute__((aligned(16))) char d2d_plug_lds[];
 
 // LDS per wave of k_plan: 6 planes of ncap doubles (active trackers) + 128 ints (path)
 __host__ __device__ inline int plan_wave_bytes(int N) {
@@ -315,13 +314,9 @@ __host__ __device__ inline int plan_wave_bytes(int N) {
   return 6 * 8 * ncap + 128 * 4;
 }
 
-__global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK) void k_plan(d2d_cfg c, d2d_state s, d2d_plan p) {
-  const int lane = threadIdx.x & (WAVE - 1);
-  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);
-  const int e = blockIdx.x * WAVES_PER_BLOCK + wv;
-  if (e >= c.B) return;
+// replan_check + plan + head waypoint of env e by one wave; `base`: plan_wave_bytes(N) bytes of LDS
+__device__ __forceinline__ void plan_env(const d2d_cfg &c, const d2d_state &s, const d2d_plan &p, int e, int lane, char *base) {
   const int N = c.N, ncap = ((N > 0 ? N : 1) + 3) & ~3;
-  char *base = d2d_plug_lds + (size_t)wv * plan_wave_bytes(N);
   TrkView T;
   T.mx = (double *)base;
   T.my = T.mx + ncap;
@@ -416,6 +411,14 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK) void k_plan(d2d_cfg c, d2d_s
   }
 }
 
+__global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK) void k_plan(d2d_cfg c, d2d_state s, d2d_plan p) {
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);
+  const int e = blockIdx.x * WAVES_PER_BLOCK + wv;
+  if (e >= c.B) return;
+  plan_env(c, s, p, e, lane, d2d_lds + (size_t)wv * plan_wave_bytes(c.N));
+}
+
 // ------------------------------------------------------------------------------------------------
 // Oxford
 // ------------------------------------------------------------------------------------------------
@@ -433,14 +436,43 @@ __device__ __forceinline__ bool acos_le(const d2d_plan &p, double q) {
   return ((p.acos_mask >> (int)(k - p.acos_key_lo)) & 1ull) != 0ull;
 }
 
-// Oxford.get_view_map (yaw_planner.py:67-79) for the cell whose origin is (x, y)
-__device__ __forceinline__ bool view_cell(const d2d_plan &p, double depth2, double x0, double y0, double cy, double sy,
-                                          double x, double y) {
+// Oxford.get_view_map (yaw_planner.py:67-79) for the cell whose origin is (x, y).
+// The literal test is arccos(dot / sqrt(d2)) <= half_fov (through the host's window) and d2 <= depth^2.  For a
+// view cone narrower than 180 degrees (cos_half > 0) the window sits at q ~ cos_half > 0, so a cell is settled
+// without the square root and the division whenever dot^2 and cos_half^2 d2 differ by more than 1e-12 relative
+// (the window is 64 ulp ~ 7e-15 wide and the roundings of both sides stay below 1e-15): only cells within
+// 1e-12 of the cone's edge or of its axis take the literal path.  `quick` is 0 when the shortcut does not apply.
+struct ViewCone {
+  double cy, sy;   // view direction: cos(radians(yaw)), -sin(radians(yaw))
+};
+
+__device__ __forceinline__ bool view_cell(const d2d_plan &p, double depth2, double quick, double x0, double y0,
+                                          const ViewCone &v, double x, double y) {
   const double a = x0 - x, b = y0 - y;
   const double d2 = a * a + b * b;
   if (d2 <= 0.0) return true;
-  const double q = ((x - x0) * cy + (y - y0) * sy) / sqrt(d2);
-  return acos_le(p, q) && d2 <= depth2;
+  if (!(d2 <= depth2)) return false;
+  const double dot = (x - x0) * v.cy + (y - y0) * v.sy;
+  if (quick > 0.0) {
+    const double lhs = dot * dot, rhs = quick * d2;  // quick = cos_half^2
+    // inside for sure: well above the edge AND q well below 1 (dead ahead q can round above 1, where arccos is NaN
+    // and the reference's comparison false: those cells take the literal path too)
+    if (dot > 0.0 && lhs > rhs * (1.0 + 1e-12) && lhs < d2 * (1.0 - 1e-12)) return true;
+    if (dot <= 0.0 || lhs < rhs * (1.0 - 1e-12)) return false;
+  }
+  return acos_le(p, dot / sqrt(d2));
+}
+
+// plugin state of env e back to "fresh objects" (experiment.py:31-34)
+__device__ __forceinline__ void plan_reset_env(const d2d_cfg &c, const d2d_plan &p, size_t e, int lane) {
+  const size_t N = (size_t)(c.N > 0 ? c.N : 1), WH = (size_t)c.W * c.H;
+  if (p.traj_hdr && lane < 2) p.traj_hdr[e * 2 + lane] = 0;
+  for (size_t k = lane; k < N; k += WAVE) {
+    if (p.trk_radius && p.trk_radius0) p.trk_radius[e * N + k] = p.trk_radius0[e * N + k];
+    if (p.trk_prev) p.trk_prev[e * N + k] = 0;
+  }
+  if (p.seen_step)
+    for (size_t i = lane; i < WH; i += WAVE) p.seen_step[e * WH + i] = 0;
 }
 
 struct GazeGeom {
@@ -459,13 +491,18 @@ __host__ __device__ inline GazeGeom gaze_geom(const d2d_cfg &c, const d2d_plan &
   return g;
 }
 
-__global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK) void k_gaze(d2d_cfg c, d2d_state s, d2d_plan p) {
-  const int lane = threadIdx.x & (WAVE - 1);
-  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);
-  const int e = blockIdx.x * WAVES_PER_BLOCK + wv;
-  if (e >= c.B) return;
+// Reset-if-done + Oxford.plan of env e by one wave; `base`: gaze_geom().wave_bytes bytes of LDS.
+// `auto_reset`: an env whose previous step ended its episode (flags[D2D_F_DONE]) first goes back to the snapshot
+// `init` with fresh plugin state -- the next episode of the reference's sweeps (main.py:26-57)
+__device__ __forceinline__ void gaze_env(const d2d_cfg &c, const d2d_state &s, const d2d_plan &p, const d2d_state &init,
+                                         int auto_reset, int e, int lane, char *base) {
+  if (auto_reset && s.flags[(size_t)e * 4 + D2D_F_DONE] != 0) {
+    reset_env(c, s, init, (size_t)e, lane);
+    plan_reset_env(c, p, (size_t)e, lane);
+    wave_sync_global();
+  }
+  if (p.gaze != D2D_GAZE_OXFORD) return;
   const GazeGeom g = gaze_geom(c, p);
-  char *base = d2d_plug_lds + (size_t)wv * g.wave_bytes;
   double *rew = (double *)base;                                   // [ncell]
   double *lsum = rew + g.ncell;                                   // [n_yaw][pw_nleaf]
   double *stk = lsum + p.n_yaw * p.pw_nleaf;                      // [n_yaw][16]
@@ -485,9 +522,14 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK) void k_gaze(d2d_cfg c, d2d_s
     return;
   }
   const FastDiv fdb(g.bbn);
+  // shortcut of view_cell: only for cones narrower than 180 degrees whose edge is well inside (0, 1)
+  const double ch = d2d_cos(p.half_fov);
+  const double quick = (p.half_fov < 1.5 && ch > 0.05) ? ch * ch : 0.0;
   // ---- t_i: cells the current pose sees (yaw_planner.py:93-97); only the box around the drone can be seen ----
   {
-    const double cy = d2d_cos(yaw * deg2rad), sy = -d2d_sin(yaw * deg2rad);  // :71
+    ViewCone vc;
+    vc.cy = d2d_cos(yaw * deg2rad);  // :71
+    vc.sy = -d2d_sin(yaw * deg2rad);
     const int bi = (int)floor((x0 - c.depth) * inv_scale) - 1, bj = (int)floor((y0 - c.depth) * inv_scale) - 1;
     for (int q0 = 0; q0 < g.ncell; q0 += WAVE) {
       const int q = q0 + lane;
@@ -495,7 +537,7 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK) void k_gaze(d2d_cfg c, d2d_s
       fdb.divmod(q, r, cc);
       const int i = bi + r, j = bj + cc;
       if (q < g.ncell && i >= 0 && i < W && j >= 0 && j < H) {
-        if (view_cell(p, depth2, x0, y0, cy, sy, (double)i * c.scale, (double)j * c.scale)) seen[i * H + j] = call;
+        if (view_cell(p, depth2, quick, x0, y0, vc, (double)i * c.scale, (double)j * c.scale)) seen[i * H + j] = call;
       }
     }
   }
@@ -523,16 +565,24 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK) void k_gaze(d2d_cfg c, d2d_s
   }
   wave_sync_lds();
   // ---- reward (:109-111) and the candidates' view bits for every box cell ----
-  double cyc[8], syc[8];
+  // the candidates' view directions: lane a evaluates candidate a, the wave shares them through LDS
+  double *vdir = stk;  // [8][2], free until the add stacks are used
+  if (lane < 8) {
+    double cyv = 0.0, syv = 0.0;
+    if (lane < p.n_yaw) {
+      const double ty = py_mod360(yaw + p.yaw_space[lane] * c.dt);  // :114, Drone2D.__init__ `% 360` (utils.py:718)
+      cyv = d2d_cos(ty * deg2rad);
+      syv = -d2d_sin(ty * deg2rad);
+    }
+    vdir[2 * lane] = cyv;
+    vdir[2 * lane + 1] = syv;
+  }
+  wave_sync_lds();
+  ViewCone cone[8];
 #pragma unroll
   for (int a = 0; a < 8; ++a) {
-    cyc[a] = 0.0;
-    syc[a] = 0.0;
-    if (a < p.n_yaw) {
-      const double ty = py_mod360(yaw + p.yaw_space[a] * c.dt);  // :114, Drone2D.__init__ `% 360` (utils.py:718)
-      cyc[a] = d2d_cos(ty * deg2rad);
-      syc[a] = -d2d_sin(ty * deg2rad);
-    }
+    cone[a].cy = vdir[2 * a];
+    cone[a].sy = vdir[2 * a + 1];
   }
   for (int q0 = 0; q0 < g.ncell; q0 += WAVE) {
     const int q = q0 + lane;
@@ -553,7 +603,7 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK) void k_gaze(d2d_cfg c, d2d_s
         const double x = (double)i * c.scale, y = (double)j * c.scale;
 #pragma unroll
         for (int a = 0; a < 8; ++a)
-          if (a < p.n_yaw && view_cell(p, depth2, hx, hy, cyc[a], syc[a], x, y)) bits |= 1u << a;
+          if (a < p.n_yaw && view_cell(p, depth2, quick, hx, hy, cone[a], x, y)) bits |= 1u << a;
       }
       rew[q] = rw;
       cm[q] = (unsigned char)bits;
@@ -635,21 +685,22 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK) void k_gaze(d2d_cfg c, d2d_s
   if (lane == 0) act[e] = p.yaw_space[best] / p.yaw_rate_max;  // :127
 }
 
-// plugin state of the masked envs back to "fresh objects" (experiment.py:31-34)
+__global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK) void k_gaze(d2d_cfg c, d2d_state s, d2d_plan p, d2d_state init,
+                                                                int auto_reset) {
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);
+  const int e = blockIdx.x * WAVES_PER_BLOCK + wv;
+  if (e >= c.B) return;
+  gaze_env(c, s, p, init, auto_reset, e, lane, d2d_lds + (size_t)wv * gaze_geom(c, p).wave_bytes);
+}
+
 __global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK) void k_plan_reset(d2d_cfg c, d2d_plan p, const unsigned char *mask,
                                                                       int mask_stride) {
   const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
   const int e = blockIdx.x * WAVES_PER_BLOCK + wv;
   if (e >= c.B) return;
   if (mask && !mask[(size_t)e * mask_stride]) return;
-  const size_t N = (size_t)(c.N > 0 ? c.N : 1), WH = (size_t)c.W * c.H;
-  if (p.traj_hdr && lane < 2) p.traj_hdr[(size_t)e * 2 + lane] = 0;
-  for (size_t k = lane; k < N; k += WAVE) {
-    if (p.trk_radius && p.trk_radius0) p.trk_radius[e * N + k] = p.trk_radius0[e * N + k];
-    if (p.trk_prev) p.trk_prev[e * N + k] = 0;
-  }
-  if (p.seen_step)
-    for (size_t i = lane; i < WH; i += WAVE) p.seen_step[e * WH + i] = 0;
+  plan_reset_env(c, p, (size_t)e, lane);
 }
 
 __global__ void k_sincos(const double *in, double *so, double *co, long long n) {

@@ -233,6 +233,8 @@ typedef struct d2d_plan {
   /* ---- scratch of the search (contents meaningless between calls) ---- */
   double *nodes;        /* [B][node_cap][D2D_NODE_F] */
   int32_t *hash;        /* [B][hash_cap] */
+  void *launch_args;    /* >= D2D_LAUNCH_ARGS_BYTES of device memory where the persistent closed-loop launch parks its
+                           arguments (NULL: d2d_closed_loop launches every stage of every step separately) */
   /* ---- diagnostics ---- */
   int32_t *plan_stat;   /* [B][4] searches run, expansions of the last search, nodes of the last search,
                            capacity overflow flag (sticky; a search that overflowed reports failure) */
@@ -240,6 +242,7 @@ typedef struct d2d_plan {
 
 /* one search node: position(2), velocity(2), cost, total_cost, acc(2), then parent slot / itr / key as raw bits */
 #define D2D_NODE_F 12
+#define D2D_LAUNCH_ARGS_BYTES 2048
 #define D2D_N_PX 0
 #define D2D_N_PY 1
 #define D2D_N_VX 2
@@ -311,9 +314,10 @@ int d2d_plan_stage(const d2d_cfg *cfg, const d2d_state *st, const d2d_plan *plan
 
 /* One closed-loop step with the plugins on the device: gaze -> perceive -> plan -> act, queued on `stream`
  * (the reference's `a = policy.plan(info); env.step(a)`, experiment.py:68-70).  `nsteps` of them back to back;
- * with `auto_reset` != 0 every env whose step ended the episode (flags[D2D_F_DONE]) is put back to the snapshot
- * `init` (and its plugin state cleared) before the next step, the way the reference's sweeps start the next
- * episode (main.py:26-57); `init` may be NULL when auto_reset == 0. */
+ * with `auto_reset` != 0 every env whose PREVIOUS step ended the episode (flags[D2D_F_DONE], so the caller sees the
+ * terminal state after the call) is put back to the snapshot `init` with fresh plugin state at the start of its
+ * next step, the way the reference's sweeps start the next episode (main.py:26-57); `init` may be NULL when
+ * auto_reset == 0. */
 int d2d_closed_loop(const d2d_cfg *cfg, const d2d_state *st, const d2d_plan *plan, int32_t nsteps,
                     int32_t auto_reset, const d2d_state *init, void *stream);
 

@@ -1032,10 +1032,6 @@ int d2d_oracle_closed_loop(const d2d_cfg *c, const d2d_state *s, const d2d_plan 
   if (rc) return rc;
   if (auto_reset && !init) return fail(-1, "closed_loop: auto_reset needs the snapshot");
   for (int t = 0; t < nsteps; ++t) {
-    if ((rc = d2d_oracle_gaze_stage(c, s, p, 0))) return rc;
-    if ((rc = d2d_oracle_run_stages(c, s, D2D_ST_PERCEIVE, 0))) return rc;
-    if ((rc = d2d_oracle_plan_stage(c, s, p, 0))) return rc;
-    if ((rc = d2d_oracle_run_stages(c, s, D2D_ST_ACT, 0))) return rc;
     if (auto_reset) { /* the next episode starts from the seeded world with fresh plugin objects (main.py:26-57) */
       uint8_t *done = (uint8_t *)malloc((size_t)c->B);
       for (int e = 0; e < c->B; ++e) done[e] = s->flags[(size_t)e * 4 + D2D_F_DONE];
@@ -1044,6 +1040,10 @@ int d2d_oracle_closed_loop(const d2d_cfg *c, const d2d_state *s, const d2d_plan 
       free(done);
       if (rc) return rc;
     }
+    if ((rc = d2d_oracle_gaze_stage(c, s, p, 0))) return rc;
+    if ((rc = d2d_oracle_run_stages(c, s, D2D_ST_PERCEIVE, 0))) return rc;
+    if ((rc = d2d_oracle_plan_stage(c, s, p, 0))) return rc;
+    if ((rc = d2d_oracle_run_stages(c, s, D2D_ST_ACT, 0))) return rc;
   }
   return 0;
 }

@@ -41,12 +41,13 @@ def test_header_constants_match_ctypes_mirror(pkg):
     names = []
     for line in body.splitlines():
         line = line.split('/*')[0]
-        m = re.match(r'\s*(?:const\s+)?(int32_t|double|int64_t|uint64_t|uint8_t)\s+\*?\s*(\w+);', line)
+        m = re.match(r'\s*(?:const\s+)?(int32_t|double|int64_t|uint64_t|uint8_t|void)\s+\*?\s*(\w+);', line)
         if m:
             names.append(m.group(2))
     assert names == [f[0] for f in A.Plan._fields_]
     assert C.sizeof(A.Plan) == 14 * 4 + 7 * 8 + 2 * 8 + (len(A.PLAN_TABLES) + len(A.PLAN_STATE)) * 8
-    for name, val in (('D2D_NODE_F', A.NODE_F), ('D2D_PLAN_PRIMITIVE', A.PLAN_PRIMITIVE), ('D2D_GAZE_OXFORD', A.GAZE_OXFORD)):
+    for name, val in (('D2D_NODE_F', A.NODE_F), ('D2D_PLAN_PRIMITIVE', A.PLAN_PRIMITIVE), ('D2D_GAZE_OXFORD', A.GAZE_OXFORD),
+                      ('D2D_LAUNCH_ARGS_BYTES', A.LAUNCH_ARGS_BYTES)):
         assert int(defs[name]) == val, name
 
 

@@ -128,8 +128,8 @@ def test_oracle_plugins_reproduce_the_reference_episode(pkg, oracle, name):
 
 
 def test_oracle_closed_loop_entry_point_and_auto_reset(pkg, oracle):
-    """d2d_closed_loop == the four stages called one by one; with auto_reset a finished episode restarts from the
-    seeded world with fresh plugin state and replays itself exactly."""
+    """d2d_closed_loop == the four stages called one by one; with auto_reset a finished episode restarts (at its next
+    step) from the seeded world with fresh plugin state and replays itself exactly."""
     from drone2d_amd import vec_env
     p = pkg.Params(planner='Primitive', gaze_method='Oxford', agent_number=10, agent_radius=15, agent_max_speed=20,
                    drone_max_speed=40, map_id=1)
@@ -139,10 +139,10 @@ def test_oracle_closed_loop_entry_point_and_auto_reset(pkg, oracle):
     yaws = []
     for t in range(T + 40):
         env.closed_loop(1, auto_reset=True)
-        k = t if t < T else t - T                 # after step T (goal reached) the episode starts over
-        if t != T - 1:                            # (at the terminal step the state was already reset)
-            assert float(env.state.drone[0, 2]) == float(fx['t_drone'][k][2]), t
-            assert np.array_equal(env.state.drone[0, :2].numpy(), fx['t_drone'][k][:2]), t
+        k = t if t < T else t - T                 # the step after the terminal one starts the episode over
+        assert float(env.state.drone[0, 2]) == float(fx['t_drone'][k][2]), t
+        assert np.array_equal(env.state.drone[0, :2].numpy(), fx['t_drone'][k][:2]), t
+        assert bool(env.state.flags[0, 3]) == bool(fx['t_done'][k]), t      # the terminal state stays visible
         yaws.append(float(env.state.drone[1, 2]))
     assert int(env.state.counters[0, pkg._abi.C_STEPS]) == 40
     # env 1 is map_id 2: a different world, also deterministic under reset
