@@ -24,6 +24,8 @@ ST_FSM, ST_AGENTS, ST_RAYCAST, ST_DYNGRID, ST_TRACKER, ST_CONTROL, ST_COLLIDE, S
 ST_PERCEIVE = ST_FSM | ST_AGENTS | ST_RAYCAST | ST_DYNGRID | ST_TRACKER
 ST_ACT = ST_CONTROL | ST_COLLIDE | ST_OBS
 ST_ALL = ST_PERCEIVE | ST_ACT
+ST_SKIP_DONE = 256
+DONE_CONTINUE, DONE_RESET, DONE_FREEZE = 0, 1, 2
 
 
 class Cfg(C.Structure):

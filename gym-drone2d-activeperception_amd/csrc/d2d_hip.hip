@@ -1212,6 +1212,7 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK, D2D_MIN_WAVES) void k_stages
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);
   const int e = blockIdx.x * wpb + wv;
   if (e >= c.B) return;
+  if ((stages & D2D_ST_SKIP_DONE) && s.flags[(size_t)e * 4 + D2D_F_DONE] != 0) return;
   const Geom g = make_geom(c, wpb, spec_ncap(SPEC));
   const LdsView L = carve(d2d_lds + (size_t)wv * g.wave_bytes, g, c.L);
   EnvRegs r;
@@ -1307,16 +1308,16 @@ struct ClosedArgs {
   d2d_state s;
   d2d_plan p;
   d2d_state init;
-  int auto_reset, nsteps;
+  int on_done, nsteps;
 };
 
-__global__ void k_closed_args(ClosedArgs *dst, d2d_cfg c, d2d_state s, d2d_plan p, d2d_state init, int auto_reset, int nsteps) {
+__global__ void k_closed_args(ClosedArgs *dst, d2d_cfg c, d2d_state s, d2d_plan p, d2d_state init, int on_done, int nsteps) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     dst->c = c;
     dst->s = s;
     dst->p = p;
     dst->init = init;
-    dst->auto_reset = auto_reset;
+    dst->on_done = on_done;
     dst->nsteps = nsteps;
   }
 }
@@ -1344,7 +1345,7 @@ __device__ __attribute__((noinline)) void ph_gaze(const ClosedArgs *ap, int e_, 
   char *base = d2d_lds + __builtin_amdgcn_readfirstlane(lds_off_);
   d2d_cfg c = a->c;
   spec_default_apply(c);
-  gaze_env(c, a->s, a->p, a->init, a->auto_reset, e, lane, base);
+  gaze_env(c, a->s, a->p, a->init, a->on_done == D2D_DONE_RESET, e, lane, base);
   wave_sync_global();
 }
 
@@ -1385,8 +1386,10 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK, D2D_MIN_WAVES) void k_closed
   const int off = wv * closed_wave_bytes<SPEC>(c, a->p);
   const bool split = a->p.planner == D2D_PLAN_PRIMITIVE;
   const int nsteps = a->nsteps;
+  const bool freeze = a->on_done == D2D_DONE_FREEZE;
 #pragma unroll 1
   for (int t = 0; t < nsteps; ++t) {
+    if (freeze && a->s.flags[(size_t)e * 4 + D2D_F_DONE] != 0) break;  // one episode per env: it stays as it ended
     ph_gaze<SPEC>(a, e, off);
     if (split) {
       ph_stages<SPEC, D2D_ST_PERCEIVE>(a, e, off);
@@ -1516,21 +1519,21 @@ int plan_check(const d2d_cfg *c, const d2d_state *s, const d2d_plan *p) {
 }
 
 // `init` != NULL: envs whose flags say "done" are first put back to the snapshot, plugin state included
-int gaze_launch(const d2d_cfg *c, const d2d_state *s, const d2d_plan *p, const d2d_state *init, void *stream) {
+int gaze_launch(const d2d_cfg *c, const d2d_state *s, const d2d_plan *p, const d2d_state *init, bool skip_done, void *stream) {
   if ((p->gaze != D2D_GAZE_OXFORD && !init) || c->B == 0) return 0;
   const dim3 grid((c->B + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK), block(WAVE * WAVES_PER_BLOCK);
   const size_t lds = p->gaze == D2D_GAZE_OXFORD ? (size_t)gaze_geom(*c, *p).wave_bytes * WAVES_PER_BLOCK : 0;
-  hipLaunchKernelGGL(k_gaze, grid, block, lds, (hipStream_t)stream, *c, *s, *p, init ? *init : *s, init ? 1 : 0);
+  hipLaunchKernelGGL(k_gaze, grid, block, lds, (hipStream_t)stream, *c, *s, *p, init ? *init : *s, init ? 1 : (skip_done ? 2 : 0));
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return fail(-3, hipGetErrorString(err));
   return 0;
 }
 
-int plan_launch(const d2d_cfg *c, const d2d_state *s, const d2d_plan *p, void *stream) {
+int plan_launch(const d2d_cfg *c, const d2d_state *s, const d2d_plan *p, bool skip_done, void *stream) {
   if (p->planner != D2D_PLAN_PRIMITIVE || c->B == 0) return 0;
   const dim3 grid((c->B + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK), block(WAVE * WAVES_PER_BLOCK);
   const size_t lds = (size_t)plan_wave_bytes(c->N) * WAVES_PER_BLOCK;
-  hipLaunchKernelGGL(k_plan, grid, block, lds, (hipStream_t)stream, *c, *s, *p);
+  hipLaunchKernelGGL(k_plan, grid, block, lds, (hipStream_t)stream, *c, *s, *p, skip_done ? 1 : 0);
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return fail(-3, hipGetErrorString(err));
   return 0;
@@ -1591,13 +1594,13 @@ int d2d_reset(const d2d_cfg *c, const d2d_state *s, const d2d_state *init, const
 int d2d_gaze_stage(const d2d_cfg *c, const d2d_state *s, const d2d_plan *p, void *stream) {
   int rc = plan_check(c, s, p);
   if (rc) return rc;
-  return gaze_launch(c, s, p, nullptr, stream);
+  return gaze_launch(c, s, p, nullptr, false, stream);
 }
 
 int d2d_plan_stage(const d2d_cfg *c, const d2d_state *s, const d2d_plan *p, void *stream) {
   int rc = plan_check(c, s, p);
   if (rc) return rc;
-  return plan_launch(c, s, p, stream);
+  return plan_launch(c, s, p, false, stream);
 }
 
 int d2d_plan_reset(const d2d_cfg *c, const d2d_plan *p, const uint8_t *mask, int32_t mask_stride, void *stream) {
@@ -1606,16 +1609,17 @@ int d2d_plan_reset(const d2d_cfg *c, const d2d_plan *p, const uint8_t *mask, int
   return plan_reset_launch(c, p, mask, mask_stride, stream);
 }
 
-int d2d_closed_loop(const d2d_cfg *c, const d2d_state *s, const d2d_plan *p, int32_t nsteps, int32_t auto_reset,
+int d2d_closed_loop(const d2d_cfg *c, const d2d_state *s, const d2d_plan *p, int32_t nsteps, int32_t on_done,
                     const d2d_state *init, void *stream) {
-  // [reset of the envs whose previous step ended the episode +] gaze -> perceive -> plan -> act per step, all
-  // queued on the stream (experiment.py:68-70): 4 launches per step, 2 when the planner stage is not on the device
+  // [reset of the envs whose previous step ended the episode +] gaze -> perceive -> plan -> act per step
   int rc = plan_check(c, s, p);
   if (rc) return rc;
   if (nsteps < 0) return fail(-1, "closed_loop: bad step count");
+  if (on_done < D2D_DONE_CONTINUE || on_done > D2D_DONE_FREEZE) return fail(-1, "closed_loop: bad on_done");
+  const bool auto_reset = on_done == D2D_DONE_RESET;
   if (auto_reset && (!init || !init->agents || !init->agent_unit || !init->dyn_prev || !init->gt || !init->dmap ||
                      !init->drone || !init->target || !init->targets || !init->counters || !init->active))
-    return fail(-1, "closed_loop: auto_reset needs the snapshot");
+    return fail(-1, "closed_loop: D2D_DONE_RESET needs the snapshot");
   if (c->B == 0 || nsteps == 0) return 0;
 #ifndef D2D_NO_PERSISTENT
   if (spec_default_matches(*c) && c->N <= spec_ncap(2) && c->planner_mode == D2D_PLANNER_EXTERNAL &&
@@ -1627,7 +1631,7 @@ int d2d_closed_loop(const d2d_cfg *c, const d2d_state *s, const d2d_plan *p, int
     if (lds <= 64 * 1024 && p->launch_args) {
       ClosedArgs *dev = (ClosedArgs *)p->launch_args;
       hipLaunchKernelGGL(k_closed_args, dim3(1), dim3(64), 0, (hipStream_t)stream, dev, *c, *s, *p, auto_reset ? *init : *s,
-                         auto_reset ? 1 : 0, (int)nsteps);
+                         (int)on_done, (int)nsteps);
       if (spec == 1) hipLaunchKernelGGL(k_closed<1>, grid, block, lds, (hipStream_t)stream, (const ClosedArgs *)dev);
       else hipLaunchKernelGGL(k_closed<2>, grid, block, lds, (hipStream_t)stream, (const ClosedArgs *)dev);
       hipError_t err = hipGetLastError();
@@ -1636,14 +1640,16 @@ int d2d_closed_loop(const d2d_cfg *c, const d2d_state *s, const d2d_plan *p, int
     }
   }
 #endif
+  // any other configuration: one launch per stage per step (4 per step, 2 when the planner stage is not on the device)
   const bool split = p->planner == D2D_PLAN_PRIMITIVE;
+  const uint32_t skip = on_done == D2D_DONE_FREEZE ? D2D_ST_SKIP_DONE : 0;
   for (int32_t t = 0; t < nsteps; ++t) {
-    if ((rc = gaze_launch(c, s, p, auto_reset ? init : nullptr, stream))) return rc;
+    if ((rc = gaze_launch(c, s, p, auto_reset ? init : nullptr, skip != 0, stream))) return rc;
     if (split) {
-      if ((rc = launch_stages(c, s, D2D_ST_PERCEIVE, stream))) return rc;
-      if ((rc = plan_launch(c, s, p, stream))) return rc;
-      if ((rc = launch_stages(c, s, D2D_ST_ACT, stream))) return rc;
-    } else if ((rc = launch_stages(c, s, D2D_ST_ALL, stream))) {
+      if ((rc = launch_stages(c, s, D2D_ST_PERCEIVE | skip, stream))) return rc;
+      if ((rc = plan_launch(c, s, p, skip != 0, stream))) return rc;
+      if ((rc = launch_stages(c, s, D2D_ST_ACT | skip, stream))) return rc;
+    } else if ((rc = launch_stages(c, s, D2D_ST_ALL | skip, stream))) {
       return rc;
     }
   }

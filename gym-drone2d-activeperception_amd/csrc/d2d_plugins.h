@@ -186,12 +186,32 @@ __device__ int plan_search(const d2d_cfg &c, const d2d_state &s, const d2d_plan 
       const double hx = ax / 2, hy = ay / 2;
       const double vex = vx + (2 * H) * hx, vey = vy + (2 * H) * hy;  // :172,183
       ok = ok && (norm2(vex, vey) < p.vmax);
-      for (int si = 0; si < p.n_sample; ++si) {  // :175-180
-        if (!__any(ok)) break;
-        const double t = p.sample_t[2 * si], t2 = p.sample_t[2 * si + 1];
-        const double sx = rint(__builtin_fma(t2, hx, px + t * vx)), sy = rint(__builtin_fma(t2, hy, py + t * vy));
-        const bool fr = plan_is_free(c, p, dm, T, sx, sy, t + (double)citr * H, inv_scale);
-        ok = ok && fr;
+      // :175-180.  Few primitives pass the speed limit (about ten of 64), so the collision samples are spread over
+      // the lanes as (primitive, sample) pairs instead of one sample round per iteration: the reference's early
+      // `break` only skips work, a successor needs ALL its samples free.
+      {
+        int *plist = chain, *pcnt = chain + WAVE;  // the path buffer is free during the search
+        const unsigned long long vm = __ballot(ok);
+        const int nv = __popcll(vm);
+        if (ok) plist[__popcll(vm & lt_mask)] = pi;
+        pcnt[lane] = 0;
+        wave_sync_lds();
+        const int npair = nv * p.n_sample;
+        for (int q0 = 0; q0 < npair; q0 += WAVE) {
+          const int q = q0 + lane;
+          if (q < npair) {
+            const int pr = q / p.n_sample, si = q - pr * p.n_sample;
+            const int spi = plist[pr];
+            const int sia = spi / p.nu, sja = spi - sia * p.nu;
+            const double shx = p.u_space[sia] / 2, shy = p.u_space[sja] / 2;
+            const double t = p.sample_t[2 * si], t2 = p.sample_t[2 * si + 1];
+            const double sx = rint(__builtin_fma(t2, shx, px + t * vx)), sy = rint(__builtin_fma(t2, shy, py + t * vy));
+            if (plan_is_free(c, p, dm, T, sx, sy, t + (double)citr * H, inv_scale)) atomicAdd(&pcnt[pr], 1);
+          }
+        }
+        wave_sync_lds();
+        if (ok) ok = pcnt[__popcll(vm & lt_mask)] == p.n_sample;
+        wave_sync_lds();
       }
       const double ex = rint((px + H * vx) + (H * H) * hx), ey = rint((py + H * vy) + (H * H) * hy);  // :182
       const double cost = ccost + (ax * ax + ay * ay) / 100 + 10;                                     // :184
@@ -411,11 +431,12 @@ __device__ __forceinline__ void plan_env(const d2d_cfg &c, const d2d_state &s, c
   }
 }
 
-__global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK) void k_plan(d2d_cfg c, d2d_state s, d2d_plan p) {
+__global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK) void k_plan(d2d_cfg c, d2d_state s, d2d_plan p, int skip_done) {
   const int lane = threadIdx.x & (WAVE - 1);
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);
   const int e = blockIdx.x * WAVES_PER_BLOCK + wv;
   if (e >= c.B) return;
+  if (skip_done && s.flags[(size_t)e * 4 + D2D_F_DONE] != 0) return;
   plan_env(c, s, p, e, lane, d2d_lds + (size_t)wv * plan_wave_bytes(c.N));
 }
 
@@ -614,15 +635,17 @@ __device__ __forceinline__ void gaze_env(const d2d_cfg &c, const d2d_state &s, c
   // lane = (candidate a, accumulator r): block by block, elements off + r + 8 k; cells outside the box contribute 0
   const int a_of = lane >> 3, r_of = lane & 7;
   const FastDiv fdh(H);
+  const bool cand = a_of < p.n_yaw;
+  const int jlo = max(bj, 0), jhi = min(bj + g.bbn, H);  // columns of the box inside the map
   for (int lf = 0; lf < p.pw_nleaf; ++lf) {
     const int off = p.pw_leaf[2 * lf], m = p.pw_leaf[2 * lf + 1];
     // rows of the box this block can touch at all
     const int i_first = off / H, i_last = (off + m - 1) / H;
-    double acc = 0.0;
     double res = 0.0;
-    if (i_last >= bi && i_first < bi + g.bbn) {
+    if (i_last >= bi && i_first < bi + g.bbn && jlo < jhi) {
       if (m < 8) {
-        if (r_of == 0 && a_of < p.n_yaw)
+        double acc = 0.0;
+        if (r_of == 0 && cand)
           for (int k = 0; k < m; ++k) {
             int gi, gj;
             fdh.divmod(off + k, gi, gj);
@@ -631,20 +654,24 @@ __device__ __forceinline__ void gaze_env(const d2d_cfg &c, const d2d_state &s, c
           }
         res = acc;
       } else {
-        const int m8 = m - (m & 7);
-        for (int k = r_of; k < m8; k += 8) {
-          int gi, gj;
-          fdh.divmod(off + k, gi, gj);
-          const int r = gi - bi, cc = gj - bj;
-          if (a_of < p.n_yaw && r >= 0 && r < g.bbn && cc >= 0 && cc < g.bbn && ((cm[r * g.bbn + cc] >> a_of) & 1))
-            acc += rew[r * g.bbn + cc];
+        // accumulator r_of of candidate a_of: elements off + r_of + 8 k in index order; only the box columns of the
+        // rows the block covers can be non-zero, so walk those (block offsets are multiples of 8: g % 8 == r_of)
+        const int m8 = m - (m & 7), gend = off + m8;
+        double acc = 0.0;
+        for (int i = max(i_first, bi); i <= min(i_last, bi + g.bbn - 1); ++i) {
+          const int glo = max(off, i * H + jlo), ghi = min(gend, i * H + jhi);
+          const int rowbase = (i - bi) * g.bbn - i * H - bj;  // box index = rowbase + g
+          for (int gq = glo + ((r_of - glo) & 7); gq < ghi; gq += 8) {
+            const int q = rowbase + gq;
+            if (cand && ((cm[q] >> a_of) & 1)) acc += rew[q];
+          }
         }
         // ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7))
         double v = acc + shfl_f64(acc, lane + 1);
         v = v + shfl_f64(v, lane + 2);
         v = v + shfl_f64(v, lane + 4);
         res = v;
-        if (r_of == 0 && a_of < p.n_yaw)
+        if (r_of == 0 && cand)
           for (int k = m8; k < m; ++k) {
             int gi, gj;
             fdh.divmod(off + k, gi, gj);
@@ -655,7 +682,7 @@ __device__ __forceinline__ void gaze_env(const d2d_cfg &c, const d2d_state &s, c
           }
       }
     }
-    if (r_of == 0 && a_of < p.n_yaw) lsum[a_of * p.pw_nleaf + lf] = res;
+    if (r_of == 0 && cand) lsum[a_of * p.pw_nleaf + lf] = res;
   }
   wave_sync_lds();
   // ---- the blocks' sums added in the recursion's order; argmax with strict >, default index 0 (:116-125) ----
@@ -685,13 +712,14 @@ __device__ __forceinline__ void gaze_env(const d2d_cfg &c, const d2d_state &s, c
   if (lane == 0) act[e] = p.yaw_space[best] / p.yaw_rate_max;  // :127
 }
 
-__global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK) void k_gaze(d2d_cfg c, d2d_state s, d2d_plan p, d2d_state init,
-                                                                int auto_reset) {
+// mode: 0 plain, 1 reset the envs that are done first, 2 leave the envs that are done untouched
+__global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK) void k_gaze(d2d_cfg c, d2d_state s, d2d_plan p, d2d_state init, int mode) {
   const int lane = threadIdx.x & (WAVE - 1);
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);
   const int e = blockIdx.x * WAVES_PER_BLOCK + wv;
   if (e >= c.B) return;
-  gaze_env(c, s, p, init, auto_reset, e, lane, d2d_lds + (size_t)wv * gaze_geom(c, p).wave_bytes);
+  if (mode == 2 && s.flags[(size_t)e * 4 + D2D_F_DONE] != 0) return;
+  gaze_env(c, s, p, init, mode == 1, e, lane, d2d_lds + (size_t)wv * gaze_geom(c, p).wave_bytes);
 }
 
 __global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK) void k_plan_reset(d2d_cfg c, d2d_plan p, const unsigned char *mask,

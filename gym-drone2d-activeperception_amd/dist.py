@@ -41,8 +41,8 @@ def init_process_group(backend=None):
     return rank, world, local
 
 
-def make_shard(params, total_envs, device=None, backend=None, planner=None, workers=0):
-    """The VecDrone2DEnv of this rank's shard of a `total_envs` global batch."""
+def make_shard(params, total_envs, device=None, backend=None, planner=None, workers=0, **env_kw):
+    """The VecDrone2DEnv of this rank's shard of a `total_envs` global batch (`env_kw`: device_plugins / gaze ...)."""
     from .vec_env import VecDrone2DEnv, build_worlds
     rank, world, local = rank_info()
     start, stop = shard_range(total_envs, rank, world)
@@ -50,7 +50,7 @@ def make_shard(params, total_envs, device=None, backend=None, planner=None, work
     if device is None:
         device = f'cuda:{local}'
     return VecDrone2DEnv(params, stop - start, device=device, planner=planner, env_offset=start,
-                         backend=backend, worlds=worlds)
+                         backend=backend, worlds=worlds, **env_kw)
 
 
 def gather_episode_stats(env, total_envs=None):

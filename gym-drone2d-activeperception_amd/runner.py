@@ -58,3 +58,58 @@ class Experiment:
             with open(self.result_dir, 'a', newline='') as f:
                 csv.writer(f).writerow(row)
         return row
+
+
+class ExperimentBatch:
+    """The reference's sweep of episodes (`main.py:26-57`: the same cfg over many map ids, one Experiment and one
+    CSV row each) as ONE device batch: env i is the world of `map_id + i`, the gaze policy and the planner run on
+    the device (Oxford / Primitive), every env plays exactly one episode (`D2D_DONE_FREEZE`) and `rows()` returns
+    the reference's CSV rows.  Everything an episode needs stays on the GPU; the host only reads the rows."""
+
+    def __init__(self, params, num_envs, device='cuda:0', backend=None, workers=0):
+        from .vec_env import VecDrone2DEnv, build_worlds
+        p = with_defaults(params)
+        if p.gaze_method not in ('Oxford',) or p.planner not in ('Primitive', 'NoMove'):
+            raise NotImplementedError('ExperimentBatch runs the device plugins: gaze_method Oxford, planner Primitive / NoMove '
+                                      '(use Experiment / HostPluginBatch for the host plugins)')
+        self.params = p
+        worlds = build_worlds(p, num_envs, workers=workers)
+        self.env = VecDrone2DEnv(p, num_envs, device=device, backend=backend, planner=p.planner, worlds=worlds,
+                                 device_plugins=True, gaze='Oxford')
+        self.max_steps = int(np.ceil(p.max_flight_time / p.dt)) + 1           # freezing ends every episode by then
+
+    def run(self, chunk=None):
+        n = self.max_steps
+        chunk = chunk or n
+        for c0 in range(0, n, chunk):
+            self.env.closed_loop(min(chunk, n - c0), freeze_done=True)
+        self.env.sync()
+        return self.rows()
+
+    def rows(self):
+        """One tuple per env with the columns of experiment.py:73-103."""
+        p, s = self.params, self.env.state
+        c = s.counters.cpu().numpy()
+        f = s.flags.cpu().numpy()
+        disc = (s.dmap != 0).flatten(1).sum(1).cpu().numpy()
+        out = []
+        for e in range(self.env.num_envs):
+            n = int(c[e, A.C_BUF_N])
+            tracking_time = float(c[e, A.C_BUF_TS]) * 0.1
+            with np.errstate(divide='ignore', invalid='ignore'):
+                mean_time = np.float64(tracking_time) / n if n else float('nan')
+            sm = int(c[e, A.C_SM])
+            out.append((p.gaze_method, p.planner, p.motion_profile, p.map_id + self.env.env_offset + e, p.agent_radius,
+                        p.agent_number, p.pillar_number, p.agent_max_speed, p.drone_max_speed, p.var_cam, p.init_position,
+                        p.target_list[0], int(c[e, A.C_STEPS]) * p.dt, int(disc[e]), n, mean_time,
+                        1 if sm == A.SM_GOAL_REACHED else 0, 1 if f[e, 0] == 1 else 0, 1 if f[e, 0] == 2 else 0,
+                        int(f[e, 2]), int(f[e, 1]), sm))
+        return out
+
+    def write_csv(self, path):
+        new = not os.path.isfile(path)
+        with open(path, 'a', newline='') as fh:
+            w = csv.writer(fh)
+            if new:
+                w.writerow(CSV_COLUMNS)
+            w.writerows(self.rows())

@@ -191,13 +191,15 @@ class VecDrone2DEnv:
                 'tracked_agent': s.counters[:, A.C_TRACKED], 'newly_tracked': s.newly, 'hit': s.hit}
         return obs, self.reward, done, info
 
-    def closed_loop(self, nsteps=1, auto_reset=False):
+    def closed_loop(self, nsteps=1, auto_reset=False, freeze_done=False):
         """`nsteps` reference-style steps with the plugins on the device: a = Oxford.plan(info); perceive;
-        Primitive.replan_check + plan; act (experiment.py:68-70).  With `auto_reset` an env whose episode ended
-        restarts from its seeded world with fresh plugin state before the next step."""
+        Primitive.replan_check + plan; act (experiment.py:68-70).  `auto_reset`: an env whose episode ended restarts
+        from its seeded world with fresh plugin state at its next step.  `freeze_done`: an env whose episode ended
+        stays as it ended (one episode per env; `episode_stats()` then holds one CSV row per env)."""
         if self.plugins is None:
             raise RuntimeError('closed_loop() needs device_plugins=True')
-        self.backend.closed_loop(self.cfg, self._st, self._plan, int(nsteps), auto_reset,
+        mode = A.DONE_RESET if auto_reset else (A.DONE_FREEZE if freeze_done else A.DONE_CONTINUE)
+        self.backend.closed_loop(self.cfg, self._st, self._plan, int(nsteps), mode,
                                  self._init_st if auto_reset else None)
         return self._result()
 

@@ -107,6 +107,12 @@ extern "C" {
 #define D2D_ST_PERCEIVE (D2D_ST_FSM | D2D_ST_AGENTS | D2D_ST_RAYCAST | D2D_ST_DYNGRID | D2D_ST_TRACKER)
 #define D2D_ST_ACT (D2D_ST_CONTROL | D2D_ST_COLLIDE | D2D_ST_OBS)
 #define D2D_ST_ALL (D2D_ST_PERCEIVE | D2D_ST_ACT)
+#define D2D_ST_SKIP_DONE 256 /* modifier: envs whose flags say "done" are left untouched by the launch */
+
+/* d2d_closed_loop `on_done`: what happens to an env whose step ended its episode (flags[D2D_F_DONE]) */
+#define D2D_DONE_CONTINUE 0 /* keeps stepping (the reference's sweeps that ignore `done`)                          */
+#define D2D_DONE_RESET 1    /* back to the snapshot with fresh plugin state at the start of its next step          */
+#define D2D_DONE_FREEZE 2   /* stays as it ended: one episode per env, the terminal state is the result (main.py)  */
 
 /* Numeric mirror of the reference's Params (utils.py:65-106) plus derived constants. */
 typedef struct d2d_cfg {
@@ -313,13 +319,14 @@ int d2d_gaze_stage(const d2d_cfg *cfg, const d2d_state *st, const d2d_plan *plan
 int d2d_plan_stage(const d2d_cfg *cfg, const d2d_state *st, const d2d_plan *plan, void *stream);
 
 /* One closed-loop step with the plugins on the device: gaze -> perceive -> plan -> act, queued on `stream`
- * (the reference's `a = policy.plan(info); env.step(a)`, experiment.py:68-70).  `nsteps` of them back to back;
- * with `auto_reset` != 0 every env whose PREVIOUS step ended the episode (flags[D2D_F_DONE], so the caller sees the
- * terminal state after the call) is put back to the snapshot `init` with fresh plugin state at the start of its
- * next step, the way the reference's sweeps start the next episode (main.py:26-57); `init` may be NULL when
- * auto_reset == 0. */
+ * (the reference's `a = policy.plan(info); env.step(a)`, experiment.py:68-70).  `nsteps` of them back to back.
+ * `on_done` (D2D_DONE_*): with RESET every env whose PREVIOUS step ended the episode (flags[D2D_F_DONE], so the
+ * caller sees the terminal state after the call) is put back to the snapshot `init` with fresh plugin state at the
+ * start of its next step, the way the reference's sweeps start the next episode (main.py:26-57); with FREEZE a
+ * finished env is left exactly as its last step left it (Experiment.run stops at done, experiment.py:68-72).
+ * `init` may be NULL unless on_done == D2D_DONE_RESET. */
 int d2d_closed_loop(const d2d_cfg *cfg, const d2d_state *st, const d2d_plan *plan, int32_t nsteps,
-                    int32_t auto_reset, const d2d_state *init, void *stream);
+                    int32_t on_done, const d2d_state *init, void *stream);
 
 /* Clears the plugin state (trajectory, tracker radii <- plan->trk_radius0, seen map) of the envs with
  * mask[e * mask_stride] != 0 (mask == NULL: all): Experiment.__init__ builds fresh plugin objects per episode

@@ -474,6 +474,7 @@ int d2d_oracle_run_stages(const d2d_cfg *c, const d2d_state *s, uint32_t stages,
 #pragma omp parallel for schedule(static) num_threads(g_threads > 0 ? g_threads : 1)
   for (int e = 0; e < c->B; ++e) {
     env_view v = view(c, s, e);
+    if ((stages & D2D_ST_SKIP_DONE) && v.flags[D2D_F_DONE]) continue;
     if (stages & D2D_ST_FSM) st_fsm(&v);
     if (stages & D2D_ST_AGENTS) st_agents(&v);
     if (stages & D2D_ST_RAYCAST) st_raycast(&v);
@@ -572,6 +573,8 @@ int d2d_oracle_tan_array(const double *in, double *out, int64_t n, void *stream)
  *   np.arccos(q) <= half_fov                    = d2d_plan.acos_key_lo / acos_mask (numpy's arccos is a SIMD
  *                                                 routine, not libm's; the host tabulates its decisions)
  * ================================================================================================= */
+
+static int g_skip_done = 0; /* set by closed_loop(D2D_DONE_FREEZE) around the plugin stages: finished envs are left alone */
 
 static uint8_t dm_get_grid(const env_view *v, double x, double y) { /* drone.map.get_grid, utils.py:545-548 */
   const d2d_cfg *c = v->c;
@@ -863,6 +866,7 @@ int d2d_oracle_plan_stage(const d2d_cfg *c, const d2d_state *s, const d2d_plan *
   for (int e = 0; e < c->B; ++e) {
     env_view v = view(c, s, e);
     plan_view q = pview(c, p, e);
+    if (g_skip_done && v.flags[D2D_F_DONE]) continue;
     /* KalmanFilter.__init__ on archive puts tracker.radius back to params.agent_radius (utils.py:184,238) */
     for (int k = 0; k < c->N; ++k) {
       if (q.trk_prev[k] && !v.active[k]) q.trk_radius[k] = p->agent_radius;
@@ -954,6 +958,7 @@ int d2d_oracle_gaze_stage(const d2d_cfg *c, const d2d_state *s, const d2d_plan *
   for (int e = 0; e < c->B; ++e) {
     env_view v = view(c, s, e);
     plan_view q = pview(c, p, e);
+    if (g_skip_done && v.flags[D2D_F_DONE]) continue;
     double *sw = (double *)malloc(sizeof(double) * WH * 2), *rew = sw + WH;
     const int call = v.cnt[D2D_C_STEPS] + 1; /* one plan() per step, before it (experiment.py:68-70) */
     if (call >= p->tobs_len) {
@@ -1025,27 +1030,31 @@ int d2d_oracle_plan_reset(const d2d_cfg *c, const d2d_plan *p, const uint8_t *ma
   return 0;
 }
 
-int d2d_oracle_closed_loop(const d2d_cfg *c, const d2d_state *s, const d2d_plan *p, int32_t nsteps, int32_t auto_reset,
+int d2d_oracle_closed_loop(const d2d_cfg *c, const d2d_state *s, const d2d_plan *p, int32_t nsteps, int32_t on_done,
                            const d2d_state *init, void *stream) {
   (void)stream;
   int rc = plan_check(c, s, p);
   if (rc) return rc;
-  if (auto_reset && !init) return fail(-1, "closed_loop: auto_reset needs the snapshot");
-  for (int t = 0; t < nsteps; ++t) {
+  const int auto_reset = on_done == D2D_DONE_RESET;
+  const uint32_t skip = on_done == D2D_DONE_FREEZE ? D2D_ST_SKIP_DONE : 0;
+  if (auto_reset && !init) return fail(-1, "closed_loop: D2D_DONE_RESET needs the snapshot");
+  g_skip_done = skip != 0;
+  for (int t = 0; t < nsteps && !rc; ++t) {
     if (auto_reset) { /* the next episode starts from the seeded world with fresh plugin objects (main.py:26-57) */
       uint8_t *done = (uint8_t *)malloc((size_t)c->B);
       for (int e = 0; e < c->B; ++e) done[e] = s->flags[(size_t)e * 4 + D2D_F_DONE];
       rc = d2d_oracle_reset(c, s, init, done, 0);
       if (!rc) rc = d2d_oracle_plan_reset(c, p, done, 1, 0);
       free(done);
-      if (rc) return rc;
+      if (rc) break;
     }
-    if ((rc = d2d_oracle_gaze_stage(c, s, p, 0))) return rc;
-    if ((rc = d2d_oracle_run_stages(c, s, D2D_ST_PERCEIVE, 0))) return rc;
-    if ((rc = d2d_oracle_plan_stage(c, s, p, 0))) return rc;
-    if ((rc = d2d_oracle_run_stages(c, s, D2D_ST_ACT, 0))) return rc;
+    if ((rc = d2d_oracle_gaze_stage(c, s, p, 0))) break;
+    if ((rc = d2d_oracle_run_stages(c, s, D2D_ST_PERCEIVE | skip, 0))) break;
+    if ((rc = d2d_oracle_plan_stage(c, s, p, 0))) break;
+    if ((rc = d2d_oracle_run_stages(c, s, D2D_ST_ACT | skip, 0))) break;
   }
-  return 0;
+  g_skip_done = 0;
+  return rc;
 }
 
 int d2d_oracle_sincos_array(const double *in, double *so, double *co, int64_t n, void *stream) {

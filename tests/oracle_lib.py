@@ -61,8 +61,8 @@ class OracleBackend:
     def plan_stage(self, cfg, st, plan):
         self._chk(self.fn['plan_stage'](C.byref(cfg), C.byref(st), C.byref(plan), None))
 
-    def closed_loop(self, cfg, st, plan, nsteps, auto_reset=False, init=None):
-        self._chk(self.fn['closed_loop'](C.byref(cfg), C.byref(st), C.byref(plan), nsteps, 1 if auto_reset else 0,
+    def closed_loop(self, cfg, st, plan, nsteps, on_done=0, init=None):
+        self._chk(self.fn['closed_loop'](C.byref(cfg), C.byref(st), C.byref(plan), nsteps, int(on_done),
                                          None if init is None else C.byref(init), None))
 
     def plan_reset(self, cfg, plan, mask=None, mask_stride=1):

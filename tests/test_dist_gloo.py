@@ -40,6 +40,58 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def _worker_closed(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port))
+    import drone2d_amd as pkg
+    from drone2d_amd import dist as d2dist
+    from oracle_lib import OracleBackend
+    d2dist.init_process_group('gloo')
+    env = d2dist.make_shard(_closed_params(pkg), 5, device='cpu', backend=OracleBackend(), planner='Primitive',
+                            device_plugins=True, gaze='Oxford')
+    env.closed_loop(CLOSED_STEPS, auto_reset=True)
+    stats = d2dist.gather_episode_stats(env, 5)
+    q.put((rank, stats.numpy(), env.state.drone.numpy().copy(), env.plugins.t['traj_hdr'].numpy().copy()))
+    import torch.distributed as dist
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+CLOSED_STEPS = 230      # past the end of the first episodes: the shards also restart them identically
+
+
+def _closed_params(pkg):
+    return pkg.Params(planner='Primitive', gaze_method='Oxford', agent_number=10, agent_radius=15, agent_max_speed=20,
+                      drone_max_speed=40, map_id=1)
+
+
+def test_closed_loop_shards_equal_one_process(pkg, oracle):
+    """The closed loop with the plugins on the device (oracle standing in for the HIP library), 5 envs over 2 ranks:
+    env identity is the global env id, so the shards reproduce the single-process batch env for env."""
+    from drone2d_amd import vec_env
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29850 + os.getpid() % 100
+    procs = [ctx.Process(target=_worker_closed, args=(r, 2, port, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    got = {}
+    for _ in range(2):
+        r, stats, drone, hdr = q.get(timeout=300)
+        got[r] = (stats, drone, hdr)
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    ref = vec_env.VecDrone2DEnv(_closed_params(pkg), 5, backend=oracle, planner='Primitive', device_plugins=True, gaze='Oxford')
+    ref.closed_loop(CLOSED_STEPS, auto_reset=True)
+    want = ref.episode_stats().numpy()
+    assert np.array_equal(got[0][0], want) and np.array_equal(got[1][0], want)
+    assert np.array_equal(np.concatenate([got[0][1], got[1][1]]), ref.state.drone.numpy())
+    assert np.array_equal(np.concatenate([got[0][2], got[1][2]]), ref.plugins.t['traj_hdr'].numpy())
+
+
 def test_two_shards_equal_one_process(pkg, oracle):
     from drone2d_amd import vec_env, dist as d2dist
     assert d2dist.shard_range(7, 0, 2) == (0, 4) and d2dist.shard_range(7, 1, 2) == (4, 7)

@@ -38,3 +38,39 @@ def test_csv_file_written(pkg, oracle, tmp_path):
     runner.Experiment(p, str(out), backend=oracle).run()
     lines = out.read_text().strip().splitlines()
     assert lines[0].split(',')[0] == 'Method' and len(lines) == 2 and lines[1].startswith('Rotating,Primitive,CVM,2,')
+
+
+def _batch_rows(pkg, backend, device, B=4):
+    """ExperimentBatch (plugins on the device, one frozen episode per env) vs the reference's row for map_id 1 and vs
+    stand-alone Experiment runs (host plugin objects) for the other map ids."""
+    from drone2d_amd import runner
+    fx = load('experiment_rows')
+    kw = json.loads(str(fx['r0_cfg']))
+    p = pkg.Params(debug=True, **kw)
+    p.render = False
+    eb = runner.ExperimentBatch(p, B, device=device, backend=backend)
+    rows = eb.run()
+    assert all(int(d) for d in eb.env.state.flags[:, 3].cpu())                      # every episode ended
+    got0 = np.array([float(v) for v in rows[0][12:]], dtype=np.float64)
+    assert np.allclose(got0, fx['r0_row'], rtol=0, atol=1e-9, equal_nan=True), (got0, fx['r0_row'])
+    for e in range(1, B):
+        q = pkg.Params(debug=True, **dict(kw, map_id=kw['map_id'] + e))
+        q.render = False
+        want = runner.Experiment(q, device=device, backend=backend).run()
+        a = np.array([float(v) for v in rows[e][12:]], dtype=np.float64)
+        b = np.array([float(v) for v in want[12:]], dtype=np.float64)
+        assert rows[e][3] == want[3] and np.allclose(a, b, rtol=0, atol=1e-9, equal_nan=True), (e, a, b)
+    # a second run() call changes nothing: finished envs stay frozen
+    before = eb.env.state.drone.clone()
+    eb.env.closed_loop(5, freeze_done=True)
+    eb.env.sync()
+    assert np.array_equal(before.cpu().numpy(), eb.env.state.drone.cpu().numpy())
+
+
+def test_experiment_batch_rows_cpu(pkg, oracle):
+    _batch_rows(pkg, oracle, 'cpu', B=3)
+
+
+@pytest.mark.gpu
+def test_experiment_batch_rows_gpu(pkg, hip):
+    _batch_rows(pkg, hip, hip.device, B=6)
