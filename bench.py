@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — env-steps/s of the batched Drone2D environment on MI355X (BASELINE.json metric).
 
-  python bench.py --gpus 1 --steps 600 --warmup 100
+  python bench.py --gpus 1 --steps 600 --warmup 300
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W
 
@@ -145,7 +145,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=600)
-    ap.add_argument('--warmup', type=int, default=100)
+    ap.add_argument('--warmup', type=int, default=300)
     ap.add_argument('--envs', type=int, default=4096, help='envs per GPU')
     ap.add_argument('--agents', type=int, default=10)
     ap.add_argument('--static-map', default='maps/empty_map.npy', help='exploration only: other BASELINE configs')

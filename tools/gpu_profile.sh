@@ -7,7 +7,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG; rm -rf "$OUT"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 600 --warmup 100 --no-cpu-baseline --workers 0 ${BENCH_ARGS:-}"
+ARGS="--steps 600 --warmup 300 --no-cpu-baseline --workers 0 ${BENCH_ARGS:-}"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/ktrace" -- python3 "$ROOT/bench.py" $ARGS > "$OUT/ktrace.log" 2>&1
 for ctr in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --pmc $ctr --output-format csv -d "$OUT/pmc_$ctr" -- python3 "$ROOT/bench.py" $ARGS > "$OUT/pmc_$ctr.log" 2>&1
