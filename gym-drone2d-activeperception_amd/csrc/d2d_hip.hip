@@ -1325,7 +1325,7 @@ __global__ void k_closed_args(ClosedArgs *dst, d2d_cfg c, d2d_state s, d2d_plan 
 template <int SPEC>
 __host__ __device__ inline int closed_wave_bytes(const d2d_cfg &c, const d2d_plan &p) {
   int b = make_geom(c, WAVES_PER_BLOCK, spec_ncap(SPEC)).wave_bytes;
-  const int pb = plan_wave_bytes(c.N), gb = p.gaze == D2D_GAZE_OXFORD ? gaze_geom(c, p).wave_bytes : 0;
+  const int pb = plan_wave_bytes(c.N, p.nu, p.n_sample, c.W * c.H), gb = p.gaze == D2D_GAZE_OXFORD ? gaze_geom(c, p).wave_bytes : 0;
   b = b > pb ? b : pb;
   b = b > gb ? b : gb;
   return (b + 15) & ~15;
@@ -1504,13 +1504,13 @@ int plan_check(const d2d_cfg *c, const d2d_state *s, const d2d_plan *p) {
     if (p->nu <= 0 || p->n_sample <= 0 || p->n_ts <= 0 || p->traj_cap < p->n_ts || p->node_cap < 2)
       return fail(-1, "plan: bad planner dimensions");
     if (!s->plan_ok || !s->wp_valid || !s->wp) return fail(-1, "plan: plan_ok / wp_valid / wp buffers missing");
-    if ((size_t)plan_wave_bytes(c->N) * WAVES_PER_BLOCK > 64 * 1024) return fail(-4, "plan: too many agents for the tracker staging in LDS");
+    if ((size_t)plan_wave_bytes(c->N, p->nu, p->n_sample, c->W * c->H) * WAVES_PER_BLOCK > 64 * 1024) return fail(-4, "plan: too many agents for the tracker staging in LDS");
   }
   if (p->gaze == D2D_GAZE_OXFORD) {
-    if (!p->yaw_space || !p->tobs_tab || !p->pw_leaf || !p->pw_prog || !p->seen_step) return fail(-1, "plan: null gaze pointer");
+    if (!p->yaw_space || !p->tobs_tab || !p->pw_leaf || !p->pw_tree || !p->pw_rowleaf || !p->seen_step) return fail(-1, "plan: null gaze pointer");
     if (!s->action) return fail(-1, "plan: null action buffer");
-    if (p->n_yaw <= 0 || p->n_yaw > 8) return fail(-4, "gaze: at most 8 yaw-rate candidates");
-    if (p->pw_nleaf <= 0 || p->pw_nprog != 2 * p->pw_nleaf - 1) return fail(-1, "gaze: bad pairwise-sum program");
+    if (p->n_yaw <= 0 || p->n_yaw > 7) return fail(-4, "gaze: at most 7 yaw-rate candidates");
+    if (p->pw_nleaf <= 0 || p->pw_nprog != 2 * p->pw_nleaf - 1 || p->pw_ntree < 3) return fail(-1, "gaze: bad pairwise-sum program");
     if ((size_t)gaze_geom(*c, *p).wave_bytes * WAVES_PER_BLOCK > 64 * 1024)
       return fail(-4, "gaze: map / view depth too large for the per-env LDS working set");
     if (c->max_steps + 2 > (double)p->tobs_len) return fail(-1, "gaze: tobs_tab shorter than the longest episode");
@@ -1532,7 +1532,7 @@ int gaze_launch(const d2d_cfg *c, const d2d_state *s, const d2d_plan *p, const d
 int plan_launch(const d2d_cfg *c, const d2d_state *s, const d2d_plan *p, bool skip_done, void *stream) {
   if (p->planner != D2D_PLAN_PRIMITIVE || c->B == 0) return 0;
   const dim3 grid((c->B + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK), block(WAVE * WAVES_PER_BLOCK);
-  const size_t lds = (size_t)plan_wave_bytes(c->N) * WAVES_PER_BLOCK;
+  const size_t lds = (size_t)plan_wave_bytes(c->N, p->nu, p->n_sample, c->W * c->H) * WAVES_PER_BLOCK;
   hipLaunchKernelGGL(k_plan, grid, block, lds, (hipStream_t)stream, *c, *s, *p, skip_done ? 1 : 0);
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return fail(-3, hipGetErrorString(err));
@@ -1555,6 +1555,16 @@ extern "C" {
 #ifdef D2D_STAMPS
 int d2d_debug_set_stamps(unsigned long long *buf) {
   return hipMemcpyToSymbol(HIP_SYMBOL(d2d_stamp_buf), &buf, sizeof(buf)) == hipSuccess ? 0 : -3;
+}
+#endif
+
+#ifdef D2D_SEARCH_PROF
+int d2d_debug_search_prof(unsigned long long *out16, int reset) {
+  if (reset) {
+    unsigned long long z[16] = {0};
+    return hipMemcpyToSymbol(HIP_SYMBOL(d2d_search_prof), z, sizeof z) == hipSuccess ? 0 : -3;
+  }
+  return hipMemcpyFromSymbol(out16, HIP_SYMBOL(d2d_search_prof), 16 * sizeof(unsigned long long)) == hipSuccess ? 0 : -3;
 }
 #endif
 

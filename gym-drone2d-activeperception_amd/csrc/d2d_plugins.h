@@ -38,21 +38,41 @@ __device__ __forceinline__ long long shfl_i64(long long v, int src) {
   return ((long long)hi << 32) | (unsigned int)lo;
 }
 
-// drone.map.get_grid (utils.py:545-548) on the explored map; NaN coordinates are refused before this is called
-__device__ __forceinline__ bool dm_is_wall(const d2d_cfg &c, const unsigned char *__restrict__ dm, double x, double y,
-                                           double inv_scale) {
+// drone.map.get_grid (utils.py:545-548) on the explored map; NaN coordinates are refused before this is called.
+// The load is unconditional (clamped address) so that the five probes of one is_free() are in flight together.
+// DM: `const unsigned char *` in global memory, or the LDS copy the search stages (address-space inferred).
+template <typename DM>
+__device__ __forceinline__ bool dm_is_wall(const d2d_cfg &c, DM dm, double x, double y, double inv_scale) {
   const bool oob = (x >= c.W_px || x < 0.0 || y >= c.H_px || y < 0.0);
   const int ci = min(max(cell_fast(x, c.scale, inv_scale), 0), c.W - 1), cj = min(max(cell_fast(y, c.scale, inv_scale), 0), c.H - 1);
-  return oob || dm[ci * c.H + cj] == D2D_OCCUPIED;
+  const unsigned char v = dm[ci * c.H + cj];
+  return oob | (v == D2D_OCCUPIED);
 }
 
 struct TrkView {  // active trackers of the env, compacted into LDS
-  double *mx, *my, *vx, *vy, *lim_plan, *lim_replan;
+  double *mx, *my, *vx, *vy;
+  double *lim_plan, *lim_replan;  // norm(d) <= L rewritten as d.d <= T(L), see sq_threshold
   int n;
 };
 
+// The largest double s with sqrt(s) <= L (sqrt correctly rounded, hence monotone): `norm(d) <= L` with numpy's
+// norm = sqrt(fma(dy, dy, dx * dx)) is exactly `fma(dy, dy, dx * dx) <= sq_threshold(L)`, without the square root in
+// the inner loops.  L * L is within a few ulp of the answer; the walk is bounded.
+__device__ __forceinline__ double sq_threshold(double L) {
+  if (!(L >= 0.0)) return -1.0;  // nothing is <= a negative or NaN limit
+  double t = L * L;
+  for (int k = 0; k < 8 && sqrt(t) > L; ++k) t = __longlong_as_double(__double_as_longlong(t) - 1);
+  for (int k = 0; k < 8; ++k) {
+    const double u = __longlong_as_double(__double_as_longlong(t) + 1);
+    if (!(sqrt(u) <= L)) break;
+    t = u;
+  }
+  return t;
+}
+
 // Planner.is_free, traj_planner.py:28-59
-__device__ __forceinline__ bool plan_is_free(const d2d_cfg &c, const d2d_plan &p, const unsigned char *__restrict__ dm,
+template <typename DM>
+__device__ __forceinline__ bool plan_is_free(const d2d_cfg &c, const d2d_plan &p, DM dm,
                                              const TrkView &T, double x, double y, double t, double inv_scale) {
   if (x != x || y != y) return false;
   const double d = p.safe_dist;
@@ -64,23 +84,20 @@ __device__ __forceinline__ bool plan_is_free(const d2d_cfg &c, const d2d_plan &p
   bool hit = false;
   for (int q = 0; q < T.n; ++q) {
     const double ex = T.mx[q] + t * T.vx[q], ey = T.my[q] + t * T.vy[q];  // estimate_pos, utils.py:220-223
-    hit = hit | (norm2(x - ex, y - ey) <= T.lim_plan[q]);
+    const double dx = x - ex, dy = y - ey;
+    hit = hit | (__builtin_fma(dy, dy, dx * dx) <= T.lim_plan[q]);
   }
   return !wall && !hit;
 }
 
-__device__ __forceinline__ long long py_ifloordiv10(long long a) {
-  long long d = a / 10;
-  if ((a % 10 != 0) && (a < 0)) --d;
-  return d;
-}
-
-// Primitive_Node.get_index, traj_planner.py:93
+// Primitive_Node.get_index, traj_planner.py:93: (round(x) // 10, round(y) // 10, round(vx), round(vy)); the floor
+// division of the rounded coordinate is exact in fp64 (cell_fast), no 64-bit integer division
 __device__ __forceinline__ long long node_key(double px, double py, double vx, double vy) {
-  const long long a = py_ifloordiv10((long long)rint(px)), b = py_ifloordiv10((long long)rint(py));
-  const long long cc = (long long)rint(vx), d = (long long)rint(vy);
-  return (long long)((((unsigned long long)(a + 32768) & 0xffffull) << 48) | (((unsigned long long)(b + 32768) & 0xffffull) << 32) |
-                     (((unsigned long long)(cc + 32768) & 0xffffull) << 16) | ((unsigned long long)(d + 32768) & 0xffffull));
+  const int a = cell_fast(rint(px), 10.0, 0.1), b = cell_fast(rint(py), 10.0, 0.1);
+  const int cc = (int)rint(vx), d = (int)rint(vy);
+  const unsigned int hi = ((unsigned int)(a + 32768) << 16) | ((unsigned int)(b + 32768) & 0xffffu);
+  const unsigned int lo = ((unsigned int)(cc + 32768) << 16) | ((unsigned int)(d + 32768) & 0xffffu);
+  return (long long)(((unsigned long long)hi << 32) | lo);
 }
 
 __device__ __forceinline__ unsigned int key_hash(long long k) {
@@ -111,19 +128,67 @@ __device__ __forceinline__ NodePlanes node_planes(double *base, int cap) {
   return n;
 }
 
+// LDS of one search (besides the trackers): small hand-off arrays so that the per-expansion chain has as few global
+// round trips and cross-lane shuffles as possible
+#ifdef D2D_SEARCH_PROF
+// Diagnostic build only (tools/search_prof.sh): shader-clock time of env 0's search per section of the expansion loop
+__device__ unsigned long long d2d_search_prof[16];
+#define SP_T(var)                                              \
+  do {                                                         \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); \
+    var = __builtin_amdgcn_s_memtime();                        \
+  } while (0)
+#define SP_ADD(idx, t0, t1) \
+  do {                      \
+    if (e == 0 && lane == 0) d2d_search_prof[idx] += (t1) - (t0); \
+  } while (0)
+#else
+#define SP_T(var) do { } while (0)
+#define SP_ADD(idx, t0, t1) do { } while (0)
+#endif
+
+struct SearchLds {
+  int *chain;       // [128] path slots; during the search [0..63] = lane of the r-th valid primitive, [64..127] = its free count
+  double *us;       // [nu] u_space
+  double *st;       // [n_sample][2] t, t**2
+  double *rv;       // [64] reduction / de-duplication values (candidate costs)
+  long long *rk;    // [64] de-duplication keys
+  int *ri;          // [64] reduction indices
+  double *tot;      // [D2D_SEARCH_LDS_NODES] total_cost of the first nodes, +inf once closed (the min() scan reads these)
+  unsigned char *map;  // [W * H] copy of the explored map for the collision probes, or null when it does not fit
+};
+
+#define D2D_SEARCH_LDS_NODES 512
+#define D2D_SEARCH_LDS_MAP 4096
+
 // Primitive.plan's search (traj_planner.py:128-218) by one wave.  Returns the number of waypoints written (0 = failure).
 __device__ int plan_search(const d2d_cfg &c, const d2d_state &s, const d2d_plan &p, int e, int lane, const TrkView &T,
-                           int *chain, const unsigned char *__restrict__ dm, double inv_scale) {
+                           const SearchLds &S, const unsigned char *__restrict__ dm, double inv_scale) {
   const double H = p.horizon;
   const NodePlanes nd = node_planes(p.nodes + (size_t)e * p.node_cap * D2D_NODE_F, p.node_cap);
   int *__restrict__ tab = p.hash + (size_t)e * p.hash_cap;
   double *__restrict__ traj = p.traj + (size_t)e * p.traj_cap * 4;
   int *stat = p.plan_stat + (size_t)e * 4;
+  int *chain = S.chain;
   const unsigned int hmask = (unsigned int)p.hash_cap - 1u;
   const double tx = s.target[(size_t)e * 2], ty = s.target[(size_t)e * 2 + 1];
   const double *dr = s.drone + (size_t)e * D2D_DF;
 
   for (int i = lane; i < p.hash_cap; i += WAVE) tab[i] = 0;
+  for (int i = lane; i < p.nu; i += WAVE) S.us[i] = p.u_space[i];
+  for (int i = lane; i < 2 * p.n_sample; i += WAVE) S.st[i] = p.sample_t[i];
+  const bool lds_map = S.map != nullptr;
+  if (lds_map) {  // the whole explored map (2.5 KB at 50 x 50): every probe of the search comes from LDS
+    const int nb = c.W * c.H;
+    if ((nb & 3) == 0 && (((size_t)dm) & 3) == 0) {
+      const unsigned int *src = (const unsigned int *)dm;
+      unsigned int *dst = (unsigned int *)S.map;
+      for (int i = lane; i < nb / 4; i += WAVE) dst[i] = src[i];
+    } else {
+      for (int i = lane; i < nb; i += WAVE) S.map[i] = dm[i];
+    }
+  }
+  const double kInf = __longlong_as_double(0x7ff0000000000000ll);
   wave_sync_global();
   if (lane == 0) {
     const double x = dr[D2D_D_X], y = dr[D2D_D_Y], vx = dr[D2D_D_VX], vy = dr[D2D_D_VY];
@@ -136,6 +201,7 @@ __device__ int plan_search(const d2d_cfg &c, const d2d_state &s, const d2d_plan 
     nd.key[0] = k;
     nd.state[0] = 1;
     tab[key_hash(k) & hmask] = 1;
+    S.tot[0] = nd.total[0];
   }
   wave_sync_global();
   int nn = 1, open_n = 1, goal = -1, itr = 0, expansions = 0;
@@ -145,36 +211,105 @@ __device__ int plan_search(const d2d_cfg &c, const d2d_state &s, const d2d_plan 
   for (;;) {
     itr += 1;
     if (open_n == 0 || itr >= p.max_itr) break;
+    unsigned long long sp0 = 0, sp1 = 0, sp2 = 0, sp3 = 0, sp4 = 0, sp5 = 0, sp6 = 0, sp7 = 0, sp8 = 0;
+    (void)sp0; (void)sp1; (void)sp2; (void)sp3; (void)sp4; (void)sp5; (void)sp6; (void)sp7; (void)sp8;
+    SP_T(sp0);
     // ---- min(open_set, key=total_cost): first minimal entry in insertion (= slot) order ----
     double best = 0.0;
     int bidx = 0x7fffffff;
-    for (int s0 = 0; s0 < nn; s0 += WAVE) {
-      const int si = s0 + lane;
-      if (si < nn && nd.state[si] == 1) {
-        const double t = nd.total[si];
-        if (bidx == 0x7fffffff || t < best) {
+    {
+      // the first D2D_SEARCH_LDS_NODES nodes from their LDS mirror (closed = +inf; an open node with an infinite or
+      // NaN cost is told apart by the state plane below, which such a search then falls back to)
+      const int nl = min(nn, D2D_SEARCH_LDS_NODES);
+      for (int s0 = 0; s0 < nl; s0 += 4 * WAVE) {
+        double t4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int si = s0 + u * WAVE + lane;
+          t4[u] = si < nl ? S.tot[si] : kInf;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int si = s0 + u * WAVE + lane;
+          if (t4[u] < kInf && (bidx == 0x7fffffff || t4[u] < best)) {
+            best = t4[u];
+            bidx = si;
+          }
+        }
+      }
+      for (int s0 = nl; s0 < nn; s0 += WAVE) {  // beyond the mirror: state and cost fetched together
+        const int si = s0 + lane;
+        const int sc = min(si, nn - 1);
+        const long long stt = nd.state[sc];
+        const double t = nd.total[sc];
+        if (si < nn && stt == 1 && (bidx == 0x7fffffff || t < best)) {
           best = t;
           bidx = si;
         }
       }
     }
-    for (int o = 32; o > 0; o >>= 1) {
-      const double t2 = shfl_f64(best, lane ^ o);
-      const int i2 = __shfl(bidx, lane ^ o, WAVE);
-      const bool take = (i2 != 0x7fffffff) && (bidx == 0x7fffffff || t2 < best || (t2 == best && i2 < bidx));
-      if (take) {
-        best = t2;
-        bidx = i2;
+    // lexicographic (cost, slot) minimum over the wave through LDS: 64 -> 8 -> 1, every lane ends with the winner
+    S.rv[lane] = best;
+    S.ri[lane] = bidx;
+    wave_sync_lds();
+    {
+      const int g0 = (lane & 7) * 8;
+      double b = S.rv[g0];
+      int bi = S.ri[g0];
+#pragma unroll
+      for (int k = 1; k < 8; ++k) {
+        const double t2 = S.rv[g0 + k];
+        const int i2 = S.ri[g0 + k];
+        if (i2 != 0x7fffffff && (bi == 0x7fffffff || t2 < b || (t2 == b && i2 < bi))) {
+          b = t2;
+          bi = i2;
+        }
       }
+      wave_sync_lds();
+      if (lane < 8) {
+        S.rv[lane] = b;
+        S.ri[lane] = bi;
+      }
+      wave_sync_lds();
+      b = S.rv[0];
+      bi = S.ri[0];
+#pragma unroll
+      for (int k = 1; k < 8; ++k) {
+        const double t2 = S.rv[k];
+        const int i2 = S.ri[k];
+        if (i2 != 0x7fffffff && (bi == 0x7fffffff || t2 < b || (t2 == b && i2 < bi))) {
+          b = t2;
+          bi = i2;
+        }
+      }
+      bidx = bi;
+      wave_sync_lds();
+    }
+    if (__builtin_amdgcn_readfirstlane(bidx) == 0x7fffffff) {
+      // every open node has a non-finite cost (wild inputs): the literal scan over the state plane decides
+      int fb = 0x7fffffff;
+      for (int s0 = 0; s0 < nn; s0 += WAVE) {
+        const int si = s0 + lane;
+        if (si < nn && nd.state[si] == 1 && fb == 0x7fffffff) fb = si;
+      }
+      for (int o = 32; o > 0; o >>= 1) fb = min(fb, __shfl_xor(fb, o, WAVE));
+      bidx = fb;
     }
     const int cur = __builtin_amdgcn_readfirstlane(bidx);
+    SP_T(sp1);
+    SP_ADD(0, sp0, sp1);
     const double px = nd.px[cur], py = nd.py[cur], vx = nd.vx[cur], vy = nd.vy[cur], ccost = nd.cost[cur];
     const int citr = nd.link[cur].y;
+    SP_T(sp2);
+    SP_ADD(1, sp1, sp2);
     if (norm2(px - tx, py - ty) <= p.goal_tol) {  // :158
       goal = cur;
       break;
     }
-    if (lane == 0) nd.state[cur] = 2;
+    if (lane == 0) {
+      nd.state[cur] = 2;
+      if (cur < D2D_SEARCH_LDS_NODES) S.tot[cur] = kInf;
+    }
     open_n -= 1;
     expansions += 1;
     // ---- expand: lane = primitive, batches of 64 in generation order (x_acc outer, y_acc inner) ----
@@ -182,18 +317,21 @@ __device__ int plan_search(const d2d_cfg &c, const d2d_state &s, const d2d_plan 
       const int pi = p0 + lane;
       bool ok = pi < nprim;
       const int ia = ok ? pi / p.nu : 0, ja = ok ? pi - ia * p.nu : 0;
-      const double ax = p.u_space[ia], ay = p.u_space[ja];
+      const double ax = S.us[ia], ay = S.us[ja];
       const double hx = ax / 2, hy = ay / 2;
       const double vex = vx + (2 * H) * hx, vey = vy + (2 * H) * hy;  // :172,183
       ok = ok && (norm2(vex, vey) < p.vmax);
       // :175-180.  Few primitives pass the speed limit (about ten of 64), so the collision samples are spread over
       // the lanes as (primitive, sample) pairs instead of one sample round per iteration: the reference's early
       // `break` only skips work, a successor needs ALL its samples free.
+      const unsigned long long vm = __ballot(ok);
+      const int myrank = __popcll(vm & lt_mask);
+      SP_T(sp3);
+      SP_ADD(2, sp2, sp3);
       {
         int *plist = chain, *pcnt = chain + WAVE;  // the path buffer is free during the search
-        const unsigned long long vm = __ballot(ok);
         const int nv = __popcll(vm);
-        if (ok) plist[__popcll(vm & lt_mask)] = pi;
+        if (ok) plist[myrank] = pi;
         pcnt[lane] = 0;
         wave_sync_lds();
         const int npair = nv * p.n_sample;
@@ -203,16 +341,21 @@ __device__ int plan_search(const d2d_cfg &c, const d2d_state &s, const d2d_plan 
             const int pr = q / p.n_sample, si = q - pr * p.n_sample;
             const int spi = plist[pr];
             const int sia = spi / p.nu, sja = spi - sia * p.nu;
-            const double shx = p.u_space[sia] / 2, shy = p.u_space[sja] / 2;
-            const double t = p.sample_t[2 * si], t2 = p.sample_t[2 * si + 1];
+            const double shx = S.us[sia] / 2, shy = S.us[sja] / 2;
+            const double t = S.st[2 * si], t2 = S.st[2 * si + 1];
             const double sx = rint(__builtin_fma(t2, shx, px + t * vx)), sy = rint(__builtin_fma(t2, shy, py + t * vy));
-            if (plan_is_free(c, p, dm, T, sx, sy, t + (double)citr * H, inv_scale)) atomicAdd(&pcnt[pr], 1);
+            const double tg = t + (double)citr * H;
+            const bool fr = lds_map ? plan_is_free(c, p, (const unsigned char *)S.map, T, sx, sy, tg, inv_scale)
+                                    : plan_is_free(c, p, dm, T, sx, sy, tg, inv_scale);
+            if (fr) atomicAdd(&pcnt[pr], 1);
           }
         }
         wave_sync_lds();
-        if (ok) ok = pcnt[__popcll(vm & lt_mask)] == p.n_sample;
+        if (ok) ok = pcnt[myrank] == p.n_sample;
         wave_sync_lds();
       }
+      SP_T(sp4);
+      SP_ADD(3, sp3, sp4);
       const double ex = rint((px + H * vx) + (H * H) * hx), ey = rint((py + H * vy) + (H * H) * hy);  // :182
       const double cost = ccost + (ax * ax + ay * ay) / 100 + 10;                                     // :184
       const long long key = node_key(ex, ey, vex, vey);
@@ -230,21 +373,45 @@ __device__ int plan_search(const d2d_cfg &c, const d2d_state &s, const d2d_plan 
           h = (h + 1) & hmask;
         }
       }
+      SP_T(sp5);
+      SP_ADD(4, sp4, sp5);
+      // the successors among themselves, through LDS (rank order = lane order = generation order): the first lane
+      // of a key owns its place in the dict, the cheapest (earliest on ties) its value
       const unsigned long long m = __ballot(ok);
+      const int nok = __popcll(m), rank = __popcll(m & lt_mask);
+      if (ok) {
+        S.rk[rank] = key;
+        S.rv[rank] = cost;
+        S.ri[rank] = lane;
+      }
+      wave_sync_lds();
       int leader = lane, wlane = -1;
       double wcost = 0.0;
-      for (unsigned long long mm = m; mm; mm &= mm - 1) {
-        const int b = __ffsll((long long)mm) - 1;
-        const long long kb = shfl_i64(key, b);
-        const double cb = shfl_f64(cost, b);
-        if (ok && kb == key) {
-          if (b < leader) leader = b;
-          if (wlane < 0 || cb < wcost) {
-            wcost = cb;
-            wlane = b;
+      for (int j0 = 0; j0 < nok; j0 += 8) {  // eight entries at a time: their LDS reads are in flight together
+        long long k8[8];
+        double c8[8];
+        int l8[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int j = min(j0 + u, nok - 1);
+          k8[u] = S.rk[j];
+          c8[u] = S.rv[j];
+          l8[u] = S.ri[j];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          if (ok && j0 + u < nok && k8[u] == key) {
+            if (l8[u] < leader) leader = l8[u];
+            if (wlane < 0 || c8[u] < wcost) {
+              wcost = c8[u];
+              wlane = l8[u];
+            }
           }
         }
       }
+      wave_sync_lds();
+      SP_T(sp6);
+      SP_ADD(5, sp5, sp6);
       const bool is_leader = ok && leader == lane;
       const bool exists = slot >= 0;
       bool closed = false;
@@ -266,7 +433,9 @@ __device__ int plan_search(const d2d_cfg &c, const d2d_state &s, const d2d_plan 
       if (write) {
         nd.px[gslot] = ex; nd.py[gslot] = ey; nd.vx[gslot] = vex; nd.vy[gslot] = vey;
         nd.cost[gslot] = cost;
-        nd.total[gslot] = cost + 0.5 * norm2(ex - tx, ey - ty) + 0.1 * norm2(vex, vey);
+        const double tot = cost + 0.5 * norm2(ex - tx, ey - ty) + 0.1 * norm2(vex, vey);
+        nd.total[gslot] = tot;
+        if (gslot < D2D_SEARCH_LDS_NODES) S.tot[gslot] = tot;
         nd.ax[gslot] = ax; nd.ay[gslot] = ay;
         nd.link[gslot] = make_int2(cur, citr + 1);
         nd.key[gslot] = key;
@@ -281,10 +450,19 @@ __device__ int plan_search(const d2d_cfg &c, const d2d_state &s, const d2d_plan 
       }
       nn += nnew;
       open_n += nnew;
-      wave_sync_global();
+      SP_T(sp7);
+      SP_ADD(6, sp6, sp7);
+      wave_sync_global();  // the next scan / probe reads what the lanes just wrote
+      SP_T(sp8);
+      SP_ADD(7, sp7, sp8);
+      SP_ADD(8, sp0, sp8);
+      if (e == 0 && lane == 0) {
+#ifdef D2D_SEARCH_PROF
+        d2d_search_prof[9] += 1;
+#endif
+      }
     }
     if (overflow) break;
-    wave_sync_global();
   }
   if (lane == 0) {
     stat[0] += 1;
@@ -327,14 +505,15 @@ __device__ int plan_search(const d2d_cfg &c, const d2d_state &s, const d2d_plan 
   return total;
 }
 
-
-// LDS per wave of k_plan: 6 planes of ncap doubles (active trackers) + 128 ints (path)
-__host__ __device__ inline int plan_wave_bytes(int N) {
+// LDS per wave of k_plan: 6 planes of ncap doubles (active trackers) + the search's hand-off arrays
+__host__ __device__ inline int plan_wave_bytes(int N, int nu, int n_sample, int WH) {
   const int ncap = ((N > 0 ? N : 1) + 3) & ~3;
-  return 6 * 8 * ncap + 128 * 4;
+  const int nu4 = (nu + 3) & ~3, ns4 = (2 * n_sample + 3) & ~3;
+  const int mapb = WH <= D2D_SEARCH_LDS_MAP ? ((WH + 15) & ~15) : 0;
+  return 6 * 8 * ncap + 8 * (nu4 + ns4) + 8 * 64 + 8 * 64 + 4 * 64 + 128 * 4 + 8 * D2D_SEARCH_LDS_NODES + mapb;
 }
 
-// replan_check + plan + head waypoint of env e by one wave; `base`: plan_wave_bytes(N) bytes of LDS
+// replan_check + plan + head waypoint of env e by one wave; `base`: plan_wave_bytes() bytes of LDS
 __device__ __forceinline__ void plan_env(const d2d_cfg &c, const d2d_state &s, const d2d_plan &p, int e, int lane, char *base) {
   const int N = c.N, ncap = ((N > 0 ? N : 1) + 3) & ~3;
   TrkView T;
@@ -344,7 +523,15 @@ __device__ __forceinline__ void plan_env(const d2d_cfg &c, const d2d_state &s, c
   T.vy = T.vx + ncap;
   T.lim_plan = T.vy + ncap;
   T.lim_replan = T.lim_plan + ncap;
-  int *chain = (int *)(T.lim_replan + ncap);
+  SearchLds S;
+  S.us = T.lim_replan + ncap;
+  S.st = S.us + ((p.nu + 3) & ~3);
+  S.rv = S.st + ((2 * p.n_sample + 3) & ~3);
+  S.rk = (long long *)(S.rv + 64);
+  S.ri = (int *)(S.rk + 64);
+  S.chain = S.ri + 64;
+  S.tot = (double *)(S.chain + 128);
+  S.map = (c.W * c.H <= D2D_SEARCH_LDS_MAP) ? (unsigned char *)(S.tot + D2D_SEARCH_LDS_NODES) : nullptr;
   const double inv_scale = 1.0 / c.scale;
   const unsigned char *__restrict__ dm = s.dmap + (size_t)e * c.W * c.H;
   // ---- trackers: archive bookkeeping (utils.py:184,238) and the active ones into LDS ----
@@ -371,8 +558,8 @@ __device__ __forceinline__ void plan_env(const d2d_cfg &c, const d2d_state &s, c
     if (act) {
       const int q = nact + __popcll(am & ((1ull << lane) - 1ull));
       T.mx[q] = m0; T.my[q] = m1; T.vx[q] = m2; T.vy[q] = m3;
-      T.lim_plan[q] = c.drone_radius + rad + 5 + c.sigma;  // traj_planner.py:58
-      T.lim_replan[q] = c.drone_radius + rad;              // traj_planner.py:228
+      T.lim_plan[q] = sq_threshold(c.drone_radius + rad + 5 + c.sigma);  // traj_planner.py:58
+      T.lim_replan[q] = sq_threshold(c.drone_radius + rad);              // traj_planner.py:228
     }
     nact += __popcll(am);
   }
@@ -398,7 +585,8 @@ __device__ __forceinline__ void plan_env(const d2d_cfg &c, const d2d_state &s, c
         if (in && sv > 0 && dm[min(max(ci, 0), c.W - 1) * c.H + min(max(cj, 0), c.H - 1)] == D2D_OCCUPIED) bad = true;
         for (int q = 0; q < nact; ++q) {
           const double ex = T.mx[q] + ti * T.vx[q], ey = T.my[q] + ti * T.vy[q];
-          if (norm2(ex - wx, ey - wy) <= T.lim_replan[q]) bad = true;
+          const double dx = ex - wx, dy = ey - wy;
+          if (__builtin_fma(dy, dy, dx * dx) <= T.lim_replan[q]) bad = true;
         }
       }
     }
@@ -408,7 +596,7 @@ __device__ __forceinline__ void plan_env(const d2d_cfg &c, const d2d_state &s, c
   int ok = 1;
   if (stored - head == 0) {
     head = 0;
-    stored = plan_search(c, s, p, e, lane, T, chain, dm, inv_scale);
+    stored = plan_search(c, s, p, e, lane, T, S, dm, inv_scale);
     ok = stored > 0 ? 1 : 0;
     wave_sync_global();
   }
@@ -437,7 +625,7 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK) void k_plan(d2d_cfg c, d2d_s
   const int e = blockIdx.x * WAVES_PER_BLOCK + wv;
   if (e >= c.B) return;
   if (skip_done && s.flags[(size_t)e * 4 + D2D_F_DONE] != 0) return;
-  plan_env(c, s, p, e, lane, d2d_lds + (size_t)wv * plan_wave_bytes(c.N));
+  plan_env(c, s, p, e, lane, d2d_lds + (size_t)wv * plan_wave_bytes(c.N, p.nu, p.n_sample, c.W * c.H));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -506,15 +694,19 @@ __host__ __device__ inline GazeGeom gaze_geom(const d2d_cfg &c, const d2d_plan &
   GazeGeom g;
   g.bbn = 2 * ((int)(c.depth / c.scale) + 1) + 3;
   g.ncell = g.bbn * g.bbn;
-  // int swept index + double reward + candidate bits per box cell, block sums + add stacks per candidate
-  const int bytes = 4 * g.ncell + 8 * g.ncell + ((g.ncell + 7) & ~7) + 8 * p.n_yaw * p.pw_nleaf + 8 * p.n_yaw * 16;
+  // int swept index + double reward + candidate bits per box cell, block sums + add stacks per candidate, the plan
+  const int bytes = 4 * g.ncell + 8 * g.ncell + ((g.ncell + 7) & ~7) + 8 * p.n_yaw * (2 * p.pw_nleaf - 1) + 8 * 16 +
+                    4 * (2 * p.pw_nleaf + p.pw_ntree);
   g.wave_bytes = (bytes + 15) & ~15;
   return g;
 }
 
 // Reset-if-done + Oxford.plan of env e by one wave; `base`: gaze_geom().wave_bytes bytes of LDS.
 // `auto_reset`: an env whose previous step ended its episode (flags[D2D_F_DONE]) first goes back to the snapshot
-// `init` with fresh plugin state -- the next episode of the reference's sweeps (main.py:26-57)
+// `init` with fresh plugin state -- the next episode of the reference's sweeps (main.py:26-57).
+// The stage is a chain of small dependent loads (table rows of sin / cos, the seen map, the pairwise plan) rather
+// than arithmetic, so loads are batched: one sin / cos pass for all seven view directions, every lane's seen-map
+// cells fetched before the first is used, the pairwise plan staged in LDS.
 __device__ __forceinline__ void gaze_env(const d2d_cfg &c, const d2d_state &s, const d2d_plan &p, const d2d_state &init,
                                          int auto_reset, int e, int lane, char *base) {
   if (auto_reset && s.flags[(size_t)e * 4 + D2D_F_DONE] != 0) {
@@ -525,10 +717,13 @@ __device__ __forceinline__ void gaze_env(const d2d_cfg &c, const d2d_state &s, c
   if (p.gaze != D2D_GAZE_OXFORD) return;
   const GazeGeom g = gaze_geom(c, p);
   double *rew = (double *)base;                                   // [ncell]
-  double *lsum = rew + g.ncell;                                   // [n_yaw][pw_nleaf]
-  double *stk = lsum + p.n_yaw * p.pw_nleaf;                      // [n_yaw][16]
-  int *swi = (int *)(stk + p.n_yaw * 16);                         // [ncell]
-  unsigned char *cm = (unsigned char *)(swi + g.ncell);           // [ncell]
+  const int nnode = 2 * p.pw_nleaf - 1;                           // blocks + their pairwise sums up to the root
+  double *lsum = rew + g.ncell;                                   // [n_yaw][nnode]
+  double *stk = lsum + p.n_yaw * nnode;                           // [8][2] view directions
+  int *swi = (int *)(stk + 16);                                   // [ncell]
+  int *pwl = swi + g.ncell;                                       // [pw_nleaf][2] + [pw_ntree]: the pairwise plan
+  int *pwp = pwl + 2 * p.pw_nleaf;
+  unsigned char *cm = (unsigned char *)(pwp + p.pw_ntree);        // [ncell]
   const int W = c.W, H = c.H;
   const double deg2rad = 0x1.1df46a2529d39p-6;                    // math.radians
   const double depth2 = c.depth * c.depth;
@@ -536,21 +731,48 @@ __device__ __forceinline__ void gaze_env(const d2d_cfg &c, const d2d_state &s, c
   const double *dr = s.drone + (size_t)e * D2D_DF;
   const double x0 = dr[D2D_D_X], y0 = dr[D2D_D_Y], yaw = dr[D2D_D_YAW];
   const int call = s.counters[(size_t)e * D2D_CF + D2D_C_STEPS] + 1;  // one plan() per step, before it
+  const int *hdr = p.traj_hdr + (size_t)e * 2;
+  const int head = hdr[0], n = hdr[1] - hdr[0];
   int *__restrict__ seen = p.seen_step + (size_t)e * W * H;
   double *act = (double *)s.action;
   if (call >= p.tobs_len) {  // refused by the host before the launch; never index past the table
     if (lane == 0) act[e] = 0.0;
     return;
   }
+  // the pairwise plan (a few hundred bytes) into LDS with one coalesced read; used only after several barriers
+  for (int k = lane; k < 2 * p.pw_nleaf; k += WAVE) pwl[k] = p.pw_leaf[k];
+  for (int k = lane; k < p.pw_ntree; k += WAVE) pwp[k] = p.pw_tree[k];
   const FastDiv fdb(g.bbn);
-  // shortcut of view_cell: only for cones narrower than 180 degrees whose edge is well inside (0, 1)
-  const double ch = d2d_cos(p.half_fov);
-  const double quick = (p.half_fov < 1.5 && ch > 0.05) ? ch * ch : 0.0;
+  // shortcut of view_cell: only for cones narrower than 180 degrees whose edge is well inside (0, 1); cos(half_fov)
+  // is the double in the middle of the host's arccos window
+  double quick = 0.0;
+  {
+    const long long k = p.acos_key_lo + 32;
+    const double ch = __longlong_as_double(k ^ ((k >> 63) & 0x7FFFFFFFFFFFFFFFll));
+    if (p.half_fov < 1.5 && ch > 0.05) quick = ch * ch;
+  }
+  // ---- the seven view directions in one pass: lane a < n_yaw = candidate a, lane 7 = the current pose (:71, :114) ----
+  double *vdir = stk;  // [8][2], free until the add stacks are used
+  if (lane < 8) {
+    double cyv = 0.0, syv = 0.0;
+    if (lane < p.n_yaw || lane == 7) {
+      // Drone2D.__init__ takes `yaw % 360` for the candidates (utils.py:718); the drone's own yaw already is
+      const double ty = (lane == 7) ? yaw : py_mod360(yaw + p.yaw_space[min(lane, p.n_yaw - 1)] * c.dt);
+      cyv = d2d_cos(ty * deg2rad);
+      syv = -d2d_sin(ty * deg2rad);
+    }
+    vdir[2 * lane] = cyv;
+    vdir[2 * lane + 1] = syv;
+  }
+  wave_sync_lds();
+  ViewCone cone[8];
+#pragma unroll
+  for (int a = 0; a < 8; ++a) {
+    cone[a].cy = vdir[2 * a];
+    cone[a].sy = vdir[2 * a + 1];
+  }
   // ---- t_i: cells the current pose sees (yaw_planner.py:93-97); only the box around the drone can be seen ----
   {
-    ViewCone vc;
-    vc.cy = d2d_cos(yaw * deg2rad);  // :71
-    vc.sy = -d2d_sin(yaw * deg2rad);
     const int bi = (int)floor((x0 - c.depth) * inv_scale) - 1, bj = (int)floor((y0 - c.depth) * inv_scale) - 1;
     for (int q0 = 0; q0 < g.ncell; q0 += WAVE) {
       const int q = q0 + lane;
@@ -558,17 +780,14 @@ __device__ __forceinline__ void gaze_env(const d2d_cfg &c, const d2d_state &s, c
       fdb.divmod(q, r, cc);
       const int i = bi + r, j = bj + cc;
       if (q < g.ncell && i >= 0 && i < W && j >= 0 && j < H) {
-        if (view_cell(p, depth2, quick, x0, y0, vc, (double)i * c.scale, (double)j * c.scale)) seen[i * H + j] = call;
+        if (view_cell(p, depth2, quick, x0, y0, cone[7], (double)i * c.scale, (double)j * c.scale)) seen[i * H + j] = call;
       }
     }
   }
-  const int *hdr = p.traj_hdr + (size_t)e * 2;
-  const int head = hdr[0], n = hdr[1] - hdr[0];
   if (n == 0) {  // :118-119
     if (lane == 0) act[e] = 0.0;
     return;
   }
-  wave_sync_global();  // the candidates read the seen map the lanes just wrote
   const double *__restrict__ traj = p.traj + (size_t)e * p.traj_cap * 4;
   const double hx = traj[(size_t)head * 4], hy = traj[(size_t)head * 4 + 1];
   const int bi = (int)floor((hx - c.depth) * inv_scale) - 1, bj = (int)floor((hy - c.depth) * inv_scale) - 1;
@@ -584,50 +803,73 @@ __device__ __forceinline__ void gaze_env(const d2d_cfg &c, const d2d_state &s, c
       if (ci >= 0 && ci < W && cj >= 0 && cj < H && r >= 0 && r < g.bbn && cc >= 0 && cc < g.bbn) atomicMax(&swi[r * g.bbn + cc], i);
     }
   }
-  wave_sync_lds();
-  // ---- reward (:109-111) and the candidates' view bits for every box cell ----
-  // the candidates' view directions: lane a evaluates candidate a, the wave shares them through LDS
-  double *vdir = stk;  // [8][2], free until the add stacks are used
-  if (lane < 8) {
-    double cyv = 0.0, syv = 0.0;
-    if (lane < p.n_yaw) {
-      const double ty = py_mod360(yaw + p.yaw_space[lane] * c.dt);  // :114, Drone2D.__init__ `% 360` (utils.py:718)
-      cyv = d2d_cos(ty * deg2rad);
-      syv = -d2d_sin(ty * deg2rad);
+  wave_sync_global();  // LDS hand-off of the swept map AND the seen map the lanes wrote above
+  // ---- reward (:109-111) and the candidates' view bits for every box cell; eight cells per lane and pass, their
+  //      seen-map entries fetched together, then their table rows, then the arithmetic ----
+  for (int q0 = 0; q0 < g.ncell; q0 += 8 * WAVE) {
+    int sn[8];
+    bool in[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int q = q0 + u * WAVE + lane;
+      int r, cc;
+      fdb.divmod(q, r, cc);
+      const int i = bi + r, j = bj + cc;
+      in[u] = q < g.ncell && i >= 0 && i < W && j >= 0 && j < H;
+      sn[u] = seen[min(max(i, 0), W - 1) * H + min(max(j, 0), H - 1)];
     }
-    vdir[2 * lane] = cyv;
-    vdir[2 * lane + 1] = syv;
-  }
-  wave_sync_lds();
-  ViewCone cone[8];
+    double tobs[8];
 #pragma unroll
-  for (int a = 0; a < 8; ++a) {
-    cone[a].cy = vdir[2 * a];
-    cone[a].sy = vdir[2 * a + 1];
-  }
-  for (int q0 = 0; q0 < g.ncell; q0 += WAVE) {
-    const int q = q0 + lane;
-    int r, cc;
-    fdb.divmod(q, r, cc);
-    const int i = bi + r, j = bj + cc;
-    if (q < g.ncell) {
-      double rw = 0.0;
-      unsigned int bits = 0;
-      if (i >= 0 && i < W && j >= 0 && j < H) {
-        const int sn = seen[i * H + j];
-        const double tobs = sn > 0 ? p.tobs_tab[call - sn] : p.tobs_tab[p.tobs_len + call];
-        const int si = swi[q];
-        const double sw = si >= 0 ? (double)si * c.dt : 0.0;
-        if (sw > 0.0 && sw <= 3.0 && tobs >= 0.5) rw = 1000000.0;
-        else if (sw > 3.0 && tobs >= 0.5) rw = 1000.0;
-        else rw = (1.0 * tobs < 1.0) ? 1.0 * tobs : 1.0;
-        const double x = (double)i * c.scale, y = (double)j * c.scale;
+    for (int u = 0; u < 8; ++u) tobs[u] = sn[u] > 0 ? p.tobs_tab[call - min(sn[u], call)] : p.tobs_tab[p.tobs_len + call];
 #pragma unroll
-        for (int a = 0; a < 8; ++a)
-          if (a < p.n_yaw && view_cell(p, depth2, quick, hx, hy, cone[a], x, y)) bits |= 1u << a;
+    for (int u = 0; u < 8; ++u) {
+      const int q = q0 + u * WAVE + lane;
+      if (q < g.ncell) {
+        double rw = 0.0;
+        unsigned int bits = 0;
+        if (in[u]) {
+          int r, cc;
+          fdb.divmod(q, r, cc);
+          const int i = bi + r, j = bj + cc;
+          const int si = swi[q];
+          const double sw = si >= 0 ? (double)si * c.dt : 0.0;
+          if (sw > 0.0 && sw <= 3.0 && tobs[u] >= 0.5) rw = 1000000.0;
+          else if (sw > 3.0 && tobs[u] >= 0.5) rw = 1000.0;
+          else rw = (1.0 * tobs[u] < 1.0) ? 1.0 * tobs[u] : 1.0;
+          // the six candidates look from the same point: distance terms once per cell, direction terms per candidate
+          const double x = (double)i * c.scale, y = (double)j * c.scale;
+          const double ca = hx - x, cb = hy - y;
+          const double d2 = ca * ca + cb * cb;
+          if (d2 <= 0.0) {
+            bits = (1u << p.n_yaw) - 1u;
+          } else if (d2 <= depth2) {
+            const double dxv = x - hx, dyv = y - hy;
+            const double rhs = quick * d2, hi = rhs * (1.0 + 1e-12), lo = rhs * (1.0 - 1e-12), top = d2 * (1.0 - 1e-12);
+            double rs = 0.0;
+            bool have_rs = false;
+#pragma unroll
+            for (int a = 0; a < 7; ++a) {
+              if (a < p.n_yaw) {
+                const double dot = dxv * cone[a].cy + dyv * cone[a].sy;
+                const double lhs = dot * dot;
+                bool in_cone;
+                if (quick > 0.0 && dot > 0.0 && lhs > hi && lhs < top) in_cone = true;
+                else if (quick > 0.0 && (dot <= 0.0 || lhs < lo)) in_cone = false;
+                else {
+                  if (!have_rs) {
+                    rs = sqrt(d2);
+                    have_rs = true;
+                  }
+                  in_cone = acos_le(p, dot / rs);
+                }
+                bits |= in_cone ? (1u << a) : 0u;
+              }
+            }
+          }
+        }
+        rew[q] = rw;
+        cm[q] = (unsigned char)bits;
       }
-      rew[q] = rw;
-      cm[q] = (unsigned char)bits;
     }
   }
   wave_sync_lds();
@@ -637,10 +879,21 @@ __device__ __forceinline__ void gaze_env(const d2d_cfg &c, const d2d_state &s, c
   const FastDiv fdh(H);
   const bool cand = a_of < p.n_yaw;
   const int jlo = max(bj, 0), jhi = min(bj + g.bbn, H);  // columns of the box inside the map
-  for (int lf = 0; lf < p.pw_nleaf; ++lf) {
-    const int off = p.pw_leaf[2 * lf], m = p.pw_leaf[2 * lf + 1];
+  // blocks the box rows can touch: a contiguous range (pw_rowleaf = block of a row's first cell); the others sum to 0
+  const int row_lo = min(max(bi, 0), W - 1), row_hi = min(max(bi + g.bbn - 1, 0), W - 1);
+  const int lf_lo = p.pw_rowleaf[row_lo];
+  int lf_hi = p.pw_rowleaf[row_hi];
+  while (lf_hi + 1 < p.pw_nleaf && pwl[2 * (lf_hi + 1)] < (row_hi + 1) * H) ++lf_hi;  // the row's last cell may sit further on
+  for (int k = lane; k < p.n_yaw * p.pw_nleaf; k += WAVE) {
+    const int a = k / p.pw_nleaf, lf = k - a * p.pw_nleaf;
+    if (lf < lf_lo || lf > lf_hi) lsum[a * nnode + lf] = 0.0;
+  }
+  for (int lf = lf_lo; lf <= lf_hi; ++lf) {
+    const int off = pwl[2 * lf], m = pwl[2 * lf + 1];
     // rows of the box this block can touch at all
-    const int i_first = off / H, i_last = (off + m - 1) / H;
+    int i_first, i_last, dummy;
+    fdh.divmod(off, i_first, dummy);
+    fdh.divmod(off + m - 1, i_last, dummy);
     double res = 0.0;
     if (i_last >= bi && i_first < bi + g.bbn && jlo < jhi) {
       if (m < 8) {
@@ -682,24 +935,26 @@ __device__ __forceinline__ void gaze_env(const d2d_cfg &c, const d2d_state &s, c
           }
       }
     }
-    if (r_of == 0 && cand) lsum[a_of * p.pw_nleaf + lf] = res;
+    if (r_of == 0 && cand) lsum[a_of * nnode + lf] = res;
   }
   wave_sync_lds();
-  // ---- the blocks' sums added in the recursion's order; argmax with strict >, default index 0 (:116-125) ----
-  double total = 0.0;
-  if (lane < p.n_yaw) {
-    double *st = stk + lane * 16;
-    int sp = 0;
-    for (int k = 0; k < p.pw_nprog; ++k) {
-      const int op = p.pw_prog[k];
-      if (op >= 0) st[sp++] = lsum[lane * p.pw_nleaf + op];
-      else {
-        sp -= 1;
-        st[sp - 1] = st[sp - 1] + st[sp];
+  // ---- the blocks' sums added in the recursion's order, level by level: the additions of one level are independent
+  //      (lane = (candidate, addition)), every single one keeps numpy's left + right; argmax below (:116-125) ----
+  {
+    const int nlev = pwp[0];
+    const int *lstart = pwp + 2, *ops = pwp + 3 + nlev;
+    for (int lv = 0; lv < nlev; ++lv) {
+      const int o0 = lstart[lv], cnt = lstart[lv + 1] - o0;
+      for (int k = lane; k < p.n_yaw * cnt; k += WAVE) {
+        const int a = k / cnt, o = o0 + (k - a * cnt);
+        const int dst = ops[3 * o], lft = ops[3 * o + 1], rgt = ops[3 * o + 2];
+        lsum[a * nnode + dst] = lsum[a * nnode + lft] + lsum[a * nnode + rgt];
       }
+      wave_sync_lds();
     }
-    total = st[0];
   }
+  double total = 0.0;
+  if (lane < p.n_yaw) total = lsum[lane * nnode + pwp[1]];
   int best = 0;
   double max_reward = 0.0;
   for (int a = 0; a < p.n_yaw; ++a) {

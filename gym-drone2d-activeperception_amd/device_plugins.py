@@ -90,6 +90,33 @@ def pairwise_plan(n):
     return np.array(leaves, dtype=np.int32).reshape(-1, 2), np.array(prog, dtype=np.int32)
 
 
+def pairwise_levels(n_leaf, prog):
+    """The add program as a tree evaluated level by level: node ids 0..n_leaf-1 are the blocks, every `-1` of the
+    program creates the next id = left + right.  Returns (ops [n_leaf - 1][3] = dst, left, right ordered by level,
+    level_start [n_levels + 1]): all ops of one level are independent, so the device adds them in parallel while
+    every single sum keeps numpy's operand order."""
+    st, nodes, height = [], [], {}
+    nxt = n_leaf
+    for op in prog:
+        if op >= 0:
+            st.append(int(op))
+            height[int(op)] = 0
+        else:
+            b = st.pop()
+            a = st.pop()
+            height[nxt] = max(height[a], height[b]) + 1
+            nodes.append((height[nxt], nxt, a, b))
+            st.append(nxt)
+            nxt += 1
+    nodes.sort(key=lambda t: (t[0], t[1]))
+    ops = np.array([[d, a, b] for _, d, a, b in nodes], dtype=np.int32).reshape(-1, 3)
+    nlev = max([h for h, *_ in nodes], default=0)
+    start = [0]
+    for lv in range(1, nlev + 1):
+        start.append(start[-1] + sum(1 for h, *_ in nodes if h == lv))
+    return ops, np.array(start, dtype=np.int32), (st[0] if st else 0)
+
+
 def pairwise_sum_host(a, leaves, prog):
     """Reference implementation of the plan (tests check it against np.sum)."""
     def leaf(off, m):
@@ -151,7 +178,13 @@ def build_tables(params, cfg):
         a5 = a5 + (1 - 0) * p.dt
     t['tobs_tab'] = tab
     leaves, prog = pairwise_plan(cfg.W * cfg.H)
+    ops, lvl_start, root = pairwise_levels(len(leaves), prog)
     t['pw_leaf'], t['pw_prog'] = leaves, prog
+    # the same additions level by level: [n_levels, root, level_start[0..n_levels], then (dst, left, right) per op]
+    t['pw_tree'] = np.concatenate([[len(lvl_start) - 1, root], lvl_start, ops.ravel()]).astype(np.int32)
+    # first block of every grid row (the blocks a view box can touch are a contiguous range)
+    offs = leaves[:, 0]
+    t['pw_rowleaf'] = np.array([int(np.searchsorted(offs, i * cfg.H, side='right') - 1) for i in range(cfg.W)], dtype=np.int32)
     half = math.radians(p.drone_view_range / 2)                                  # :72
     key_lo, mask = acos_window(half)
     # successors of one expansion satisfy |v + 2 a| < vmax: at most this many lattice points of u_space
@@ -163,7 +196,7 @@ def build_tables(params, cfg):
     hash_cap = 1 << int(math.ceil(math.log2(2 * node_cap + 2)))
     sc = dict(nu=len(u_space), n_sample=len(ts_check), n_ts=len(ts_traj), max_itr=max_itr,
               traj_cap=(max_itr - 1) * len(ts_traj), node_cap=node_cap, hash_cap=hash_cap, n_yaw=len(t['yaw_space']),
-              pw_nleaf=len(leaves), pw_nprog=len(prog), tobs_len=n_calls, reserved=0,
+              pw_nleaf=len(leaves), pw_nprog=len(prog), tobs_len=n_calls, pw_ntree=len(t['pw_tree']),
               horizon=float(horizon), vmax=float(p.drone_max_speed), safe_dist=float(p.drone_radius + 10),
               goal_tol=10.0, agent_radius=float(p.agent_radius), half_fov=half, yaw_rate_max=float(w),
               acos_key_lo=key_lo, acos_mask=mask)

@@ -211,7 +211,7 @@ typedef struct d2d_plan {
   int32_t pw_nleaf;
   int32_t pw_nprog;
   int32_t tobs_len;
-  int32_t reserved;
+  int32_t pw_ntree;
   double horizon;      /* Primitive.dt = 2 (traj_planner.py:103) */
   double vmax;         /* drone_max_speed (traj_planner.py:172) */
   double safe_dist;    /* drone_radius + 10 (traj_planner.py:32) */
@@ -229,6 +229,9 @@ typedef struct d2d_plan {
   const double *tobs_tab;
   const int32_t *pw_leaf;
   const int32_t *pw_prog;
+  const int32_t *pw_tree;    /* [pw_ntree] the additions of pw_prog level by level: n_levels, root id, level_start[n_levels + 1],
+                                then (dst, left, right) per addition; ids 0..pw_nleaf-1 are the blocks (device only) */
+  const int32_t *pw_rowleaf; /* [W] the block that holds the first cell of grid row i (device only) */
   const double *trk_radius0; /* [B][N] tracker radii of the initial world: the reset source of trk_radius */
   /* ---- per-env plugin state (read + written) ---- */
   double *traj;         /* [B][traj_cap][4] planner.trajectory: position(2), velocity(2); accelerations are 0 */

@@ -49,6 +49,12 @@ def test_pairwise_plan_is_numpy_sum(pkg):
     for W, H in ((50, 50), (64, 37), (100, 80), (9, 9), (90, 90)):
         leaves, prog = DP.pairwise_plan(W * H)
         assert len(prog) == 2 * len(leaves) - 1 and all(l[0] % 8 == 0 for l in leaves)
+        ops, start, root = DP.pairwise_levels(len(leaves), prog)
+        assert len(ops) == len(leaves) - 1 and start[-1] == len(ops) and root == (2 * len(leaves) - 2 if len(leaves) > 1 else 0)
+        done = set(range(len(leaves)))
+        for lv in range(len(start) - 1):                       # every level only reads what earlier levels produced
+            assert all(a in done and b in done for _, a, b in ops[start[lv]:start[lv + 1]])
+            done |= {int(d) for d, _, _ in ops[start[lv]:start[lv + 1]]}
         for _ in range(20):
             v = rng.choice([0, 1], size=(W, H))
             r = np.where(rng.rand(W, H) < 0.1, 1e6, np.where(rng.rand(W, H) < 0.1, 1000.0, np.clip(rng.randint(0, 60, (W, H)) * 0.1, -np.inf, 1)))
