@@ -14,6 +14,9 @@ class D2DError(RuntimeError):
 
 
 def load_library(path=LIB_PATH):
+    # torch first: its bundled HIP runtime has to be the one this library binds to.  Loaded the other way round the
+    # process ends up with two runtimes and every launch fails with "no ROCm-capable device is detected".
+    import torch  # noqa: F401
     if not os.path.isfile(path):
         raise D2DError(f'{path} not found: build it with gym-drone2d-activeperception_amd/csrc/build.sh '
                        '(or __graft_entry__.build()); there is no CPU fallback')

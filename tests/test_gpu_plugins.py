@@ -77,6 +77,7 @@ CASES = [
          drone_view_range=120, drone_view_depth=100, target_list=[[250, 250], [450, 60]]),
     dict(B=6, T=40, chunk=5, agent_number=10, agent_radius=10, agent_max_speed=40, map_id=3,
          static_map='maps/obstacle_map.npy'),
+    dict(B=5, T=60, chunk=10, agent_number=0, agent_radius=10, agent_max_speed=20, map_id=12, pillar_number=6),
 ]
 
 
@@ -98,6 +99,27 @@ def test_closed_loop_matches_oracle(pkg, hip, oracle, case):
         assert done_seen > 0 or T < 100      # the longer cases do see episodes end and restart
     finally:
         oracle_threads(1)
+
+
+@pytest.mark.parametrize('kw', [dict(agent_number=14, agent_radius=12, agent_max_speed=40, map_id=30),
+                                dict(agent_number=14, agent_radius=12, agent_max_speed=40, map_id=30, drone_view_range=100)],
+                         ids=['persistent', 'per_stage'])
+def test_freeze_mode_matches_oracle(pkg, hip, oracle, kw):
+    """D2D_DONE_FREEZE: one episode per env, finished envs stay exactly as they ended -- on the persistent kernel
+    (default geometry) and on the launch-per-stage path (any other geometry)."""
+    dev, ref = _pair(pkg, hip, oracle, 12, **kw)
+    oracle.lib.d2d_oracle_set_threads(8)
+    try:
+        for _ in range(6):
+            dev.closed_loop(40, freeze_done=True)
+            ref.closed_loop(40, freeze_done=True)
+            _assert_same(dev, ref, 'freeze')
+    finally:
+        oracle.lib.d2d_oracle_set_threads(1)
+    done = ref.state.flags[:, 3].bool()
+    assert done.any()
+    steps = ref.state.counters[:, pkg._abi.C_STEPS]
+    assert int(steps[done].max()) < 240          # they stopped where their episode ended
 
 
 def test_full_size_closed_loop_properties(pkg, hip):
