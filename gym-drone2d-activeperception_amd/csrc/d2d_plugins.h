@@ -473,7 +473,7 @@ __device__ int plan_search(const d2d_cfg &c, const d2d_state &s, const d2d_plan 
   if (goal < 0 || overflow) return 0;
   // ---- :207-216: waypoints of every primitive on the path, start side first ----
   int depth = 0;
-  for (int q = goal; q != 0; q = nd.link[q].x) depth += 1;
+  for (int q = goal; q != 0 && depth <= 128; q = nd.link[q].x) depth += 1;  // bounded: a wave must always terminate
   if (depth * p.n_ts > p.traj_cap || depth > 128) {
     if (lane == 0) stat[3] = 1;
     return 0;

@@ -190,7 +190,9 @@ typedef struct d2d_state {
  *                             was (yaw_planner.py:48,95-97); the map itself is kept as `seen_step`
  *   pw_leaf   [pw_nleaf][2]   offset, length of the <= 128-element blocks numpy's pairwise summation cuts a
  *   pw_prog   [pw_nprog]      W * H array into, and the order their partial sums are added in (>= 0: push
- *                             block, -1: add the two on top) -- np.sum(view * reward), yaw_planner.py:123
+ *                             block, -1: add the two on top) -- np.sum(view * reward), yaw_planner.py:123.
+ *                             pw_tree holds the same additions grouped by tree level (independent within a
+ *                             level), pw_rowleaf the block of every grid row's first cell: what the device reads
  *   acos_key_lo / acos_mask   np.arccos(q) <= half_fov for the 64 consecutive doubles q starting at the one whose
  *                             ordered bit pattern is acos_key_lo (bit i of the mask = decision for the i-th);
  *                             every q above the window is inside the cone, every q below outside.  numpy's
