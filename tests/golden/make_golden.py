@@ -265,7 +265,30 @@ def gen_closed():
         save(name, run_trace(p, 400, policy='Oxford'))
 
 
+def gen_live(outdir, seed0, count):
+    """Random closed-loop Oxford + Primitive episodes of the live reference into `outdir` (not committed: the
+    build-container-only test tests/test_oracle_vs_live_reference.py replays them through the oracle)."""
+    global OUT
+    OUT = outdir
+    for k in range(count):
+        rng = np.random.RandomState(seed0 + k)
+        kw = dict(agent_number=int(rng.randint(0, 26)), agent_radius=int(rng.choice([-1, 5, 8, 10, 12, 15, 18])),
+                  agent_max_speed=int(rng.choice([4, 10, 20, 30, 40, 60])), drone_max_speed=int(rng.choice([20, 30, 40, 40, 50])),
+                  map_id=int(rng.randint(0, 10000)), pillar_number=int(rng.choice([0, 0, 3, 6, 9])),
+                  drone_view_range=int(rng.choice([60, 90, 90, 120])), drone_view_depth=int(rng.choice([60, 80, 80, 100])))
+        if rng.rand() < 0.25:
+            kw['static_map'] = str(rng.choice(['maps/obstacle_map.npy', 'maps/shaped_obstacle_map.npy']))
+        if rng.rand() < 0.3:
+            kw['target_list'] = [[int(rng.randint(40, 460)), int(rng.randint(40, 460))], [int(rng.randint(40, 460)), int(rng.randint(40, 460))]]
+        if rng.rand() < 0.3:
+            kw['init_pos'] = [int(rng.randint(40, 460)), int(rng.randint(40, 460))]
+        p = make_params(gaze_method='Oxford', planner='Primitive', **kw)
+        save(f'live_oxford_{seed0 + k}', run_trace(p, 120, policy='Oxford'))
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == 'live':
+        return gen_live(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]))
     if len(sys.argv) > 1 and sys.argv[1] == 'closed':
         return gen_closed()
     if len(sys.argv) > 1 and sys.argv[1] == 'sweep':

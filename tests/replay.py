@@ -15,7 +15,8 @@ KF_TOL = 1e-6
 
 
 def load(name):
-    return np.load(os.path.join(GOLD, name + '.npz'))
+    """A committed fixture by name, or any trace file by absolute path."""
+    return np.load(name if os.path.isabs(name) else os.path.join(GOLD, name + '.npz'))
 
 
 def params_from(fx, pkg):

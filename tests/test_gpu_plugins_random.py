@@ -1,0 +1,45 @@
+"""Randomised closed-loop parity (run with -m gpu): seeded random configurations -- agent count / radius / speed, drone
+speed (other primitive sets), pillars, static maps, view cone -- device plugins vs the oracle, every field of the env
+and plugin state bit for bit, with auto reset and with freeze."""
+import numpy as np
+import pytest
+
+from test_gpu_plugins import _assert_same, _pair
+
+pytestmark = pytest.mark.gpu
+
+
+def _random_cfg(rng):
+    kw = dict(agent_number=int(rng.randint(0, 31)), agent_radius=int(rng.choice([-1, 5, 8, 10, 12, 15, 18])),
+              agent_max_speed=int(rng.choice([4, 10, 20, 30, 40, 60])), drone_max_speed=int(rng.choice([20, 30, 40, 40, 50])),
+              map_id=int(rng.randint(0, 10000)), pillar_number=int(rng.choice([0, 0, 3, 6, 9])),
+              drone_view_range=int(rng.choice([60, 90, 90, 120, 360])), drone_view_depth=int(rng.choice([60, 80, 80, 100])))
+    if rng.rand() < 0.25:
+        kw['static_map'] = str(rng.choice(['maps/obstacle_map.npy', 'maps/shaped_obstacle_map.npy']))
+    if rng.rand() < 0.3:
+        kw['target_list'] = [[int(rng.randint(40, 460)), int(rng.randint(40, 460))], [int(rng.randint(40, 460)), int(rng.randint(40, 460))]]
+    if rng.rand() < 0.3:
+        kw['init_pos'] = [int(rng.randint(40, 460)), int(rng.randint(40, 460))]
+    if rng.rand() < 0.2:
+        kw['max_flight_time'] = 6          # freezing ends episodes early
+    return kw
+
+
+@pytest.mark.parametrize('seed', range(48))
+def test_random_closed_loop_matches_oracle(pkg, hip, oracle, seed):
+    rng = np.random.RandomState(1000 + seed)
+    kw = _random_cfg(rng)
+    B, T, chunk = int(rng.choice([3, 5, 8])), 160, int(rng.choice([5, 9, 16]))
+    try:
+        dev, ref = _pair(pkg, hip, oracle, B, **kw)
+    except NotImplementedError as ex:       # e.g. a view range this host's arccos window cannot describe
+        pytest.skip(str(ex))
+    mode = dict(auto_reset=True) if seed % 3 else dict(freeze_done=True)
+    oracle.lib.d2d_oracle_set_threads(8)
+    try:
+        for t in range(0, T, chunk):
+            dev.closed_loop(chunk, **mode)
+            ref.closed_loop(chunk, **mode)
+            _assert_same(dev, ref, f'seed {seed} {kw} after step {t + chunk}')
+    finally:
+        oracle.lib.d2d_oracle_set_threads(1)
