@@ -1323,8 +1323,8 @@ __global__ void k_closed_args(ClosedArgs *dst, d2d_cfg c, d2d_state s, d2d_plan 
 }
 
 template <int SPEC>
-__host__ __device__ inline int closed_wave_bytes(const d2d_cfg &c, const d2d_plan &p) {
-  int b = make_geom(c, WAVES_PER_BLOCK, spec_ncap(SPEC)).wave_bytes;
+__host__ __device__ inline int closed_wave_bytes(const d2d_cfg &c, const d2d_plan &p, int wpb) {
+  int b = make_geom(c, wpb, spec_ncap(SPEC)).wave_bytes;
   const int pb = plan_wave_bytes(c.N, p.nu, p.n_sample, c.W * c.H), gb = p.gaze == D2D_GAZE_OXFORD ? gaze_geom(c, p).wave_bytes : 0;
   b = b > pb ? b : pb;
   b = b > gb ? b : gb;
@@ -1344,7 +1344,7 @@ __device__ __attribute__((noinline)) void ph_gaze(const ClosedArgs *ap, int e_, 
   const int e = __builtin_amdgcn_readfirstlane(e_), lane = threadIdx.x & (WAVE - 1);
   char *base = d2d_lds + __builtin_amdgcn_readfirstlane(lds_off_);
   d2d_cfg c = a->c;
-  spec_default_apply(c);
+  if (SPEC != 0) spec_default_apply(c);
   gaze_env(c, a->s, a->p, a->init, a->on_done == D2D_DONE_RESET, e, lane, base);
   wave_sync_global();
 }
@@ -1355,7 +1355,7 @@ __device__ __attribute__((noinline)) void ph_plan(const ClosedArgs *ap, int e_, 
   const int e = __builtin_amdgcn_readfirstlane(e_), lane = threadIdx.x & (WAVE - 1);
   char *base = d2d_lds + __builtin_amdgcn_readfirstlane(lds_off_);
   d2d_cfg c = a->c;
-  spec_default_apply(c);
+  if (SPEC != 0) spec_default_apply(c);
   plan_env(c, a->s, a->p, e, lane, base);
   wave_sync_global();
 }
@@ -1366,8 +1366,9 @@ __device__ __attribute__((noinline)) void ph_stages(const ClosedArgs *ap, int e_
   const int e = __builtin_amdgcn_readfirstlane(e_), lane = threadIdx.x & (WAVE - 1);
   char *base = d2d_lds + __builtin_amdgcn_readfirstlane(lds_off_);
   d2d_cfg c = a->c;
-  spec_default_apply(c);
-  const Geom g = make_geom(c, WAVES_PER_BLOCK, spec_ncap(SPEC));
+  if (SPEC != 0) spec_default_apply(c);
+  const int wpb = (SPEC == 1 || SPEC == 2) ? WAVES_PER_BLOCK : (int)(blockDim.x / WAVE);
+  const Geom g = make_geom(c, wpb, spec_ncap(SPEC));
   const LdsView L = carve(base, g, c.L);
   EnvRegs r;
   load_regs(a->s, e, r);
@@ -1379,11 +1380,12 @@ __device__ __attribute__((noinline)) void ph_stages(const ClosedArgs *ap, int e_
 template <int SPEC>
 __global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK, D2D_MIN_WAVES) void k_closed(const ClosedArgs *__restrict__ a) {
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);
-  const int e = blockIdx.x * WAVES_PER_BLOCK + wv;
+  const int wpb = (SPEC == 1 || SPEC == 2) ? WAVES_PER_BLOCK : (int)(blockDim.x / WAVE);
+  const int e = blockIdx.x * wpb + wv;
   if (e >= a->c.B) return;
   d2d_cfg c = a->c;
-  spec_default_apply(c);
-  const int off = wv * closed_wave_bytes<SPEC>(c, a->p);
+  if (SPEC != 0) spec_default_apply(c);
+  const int off = wv * closed_wave_bytes<SPEC>(c, a->p, wpb);
   const bool split = a->p.planner == D2D_PLAN_PRIMITIVE;
   const int nsteps = a->nsteps;
   const bool freeze = a->on_done == D2D_DONE_FREEZE;
@@ -1504,14 +1506,14 @@ int plan_check(const d2d_cfg *c, const d2d_state *s, const d2d_plan *p) {
     if (p->nu <= 0 || p->n_sample <= 0 || p->n_ts <= 0 || p->traj_cap < p->n_ts || p->node_cap < 2)
       return fail(-1, "plan: bad planner dimensions");
     if (!s->plan_ok || !s->wp_valid || !s->wp) return fail(-1, "plan: plan_ok / wp_valid / wp buffers missing");
-    if ((size_t)plan_wave_bytes(c->N, p->nu, p->n_sample, c->W * c->H) * WAVES_PER_BLOCK > 64 * 1024) return fail(-4, "plan: too many agents for the tracker staging in LDS");
+    if ((size_t)plan_wave_bytes(c->N, p->nu, p->n_sample, c->W * c->H) > 64 * 1024) return fail(-4, "plan: too many agents for the tracker staging in LDS");
   }
   if (p->gaze == D2D_GAZE_OXFORD) {
     if (!p->yaw_space || !p->tobs_tab || !p->pw_leaf || !p->pw_tree || !p->pw_rowleaf || !p->seen_step) return fail(-1, "plan: null gaze pointer");
     if (!s->action) return fail(-1, "plan: null action buffer");
     if (p->n_yaw <= 0 || p->n_yaw > 7) return fail(-4, "gaze: at most 7 yaw-rate candidates");
     if (p->pw_nleaf <= 0 || p->pw_nprog != 2 * p->pw_nleaf - 1 || p->pw_ntree < 3) return fail(-1, "gaze: bad pairwise-sum program");
-    if ((size_t)gaze_geom(*c, *p).wave_bytes * WAVES_PER_BLOCK > 64 * 1024)
+    if ((size_t)gaze_geom(*c, *p).wave_bytes > 64 * 1024)
       return fail(-4, "gaze: map / view depth too large for the per-env LDS working set");
     if (c->max_steps + 2 > (double)p->tobs_len) return fail(-1, "gaze: tobs_tab shorter than the longest episode");
   }
@@ -1521,8 +1523,11 @@ int plan_check(const d2d_cfg *c, const d2d_state *s, const d2d_plan *p) {
 // `init` != NULL: envs whose flags say "done" are first put back to the snapshot, plugin state included
 int gaze_launch(const d2d_cfg *c, const d2d_state *s, const d2d_plan *p, const d2d_state *init, bool skip_done, void *stream) {
   if ((p->gaze != D2D_GAZE_OXFORD && !init) || c->B == 0) return 0;
-  const dim3 grid((c->B + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK), block(WAVE * WAVES_PER_BLOCK);
-  const size_t lds = p->gaze == D2D_GAZE_OXFORD ? (size_t)gaze_geom(*c, *p).wave_bytes * WAVES_PER_BLOCK : 0;
+  const size_t wb = p->gaze == D2D_GAZE_OXFORD ? (size_t)gaze_geom(*c, *p).wave_bytes : 0;
+  int wpb = WAVES_PER_BLOCK;
+  while (wpb > 1 && wb * wpb > 64 * 1024) wpb >>= 1;
+  const dim3 grid((c->B + wpb - 1) / wpb), block(WAVE * wpb);
+  const size_t lds = wb * wpb;
   hipLaunchKernelGGL(k_gaze, grid, block, lds, (hipStream_t)stream, *c, *s, *p, init ? *init : *s, init ? 1 : (skip_done ? 2 : 0));
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return fail(-3, hipGetErrorString(err));
@@ -1531,8 +1536,11 @@ int gaze_launch(const d2d_cfg *c, const d2d_state *s, const d2d_plan *p, const d
 
 int plan_launch(const d2d_cfg *c, const d2d_state *s, const d2d_plan *p, bool skip_done, void *stream) {
   if (p->planner != D2D_PLAN_PRIMITIVE || c->B == 0) return 0;
-  const dim3 grid((c->B + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK), block(WAVE * WAVES_PER_BLOCK);
-  const size_t lds = (size_t)plan_wave_bytes(c->N, p->nu, p->n_sample, c->W * c->H) * WAVES_PER_BLOCK;
+  const size_t wb = (size_t)plan_wave_bytes(c->N, p->nu, p->n_sample, c->W * c->H);
+  int wpb = WAVES_PER_BLOCK;
+  while (wpb > 1 && wb * wpb > 64 * 1024) wpb >>= 1;
+  const dim3 grid((c->B + wpb - 1) / wpb), block(WAVE * wpb);
+  const size_t lds = wb * wpb;
   hipLaunchKernelGGL(k_plan, grid, block, lds, (hipStream_t)stream, *c, *s, *p, skip_done ? 1 : 0);
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return fail(-3, hipGetErrorString(err));
@@ -1632,18 +1640,28 @@ int d2d_closed_loop(const d2d_cfg *c, const d2d_state *s, const d2d_plan *p, int
     return fail(-1, "closed_loop: D2D_DONE_RESET needs the snapshot");
   if (c->B == 0 || nsteps == 0) return 0;
 #ifndef D2D_NO_PERSISTENT
-  if (spec_default_matches(*c) && c->N <= spec_ncap(2) && c->planner_mode == D2D_PLANNER_EXTERNAL &&
-      (p->planner == D2D_PLAN_PRIMITIVE || p->gaze == D2D_GAZE_OXFORD)) {
-    // one persistent launch: every wave loops over the steps of its own env
-    const int spec = c->N <= spec_ncap(1) ? 1 : 2;
-    const dim3 grid((c->B + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK), block(WAVE * WAVES_PER_BLOCK);
-    const size_t lds = (size_t)(spec == 1 ? closed_wave_bytes<1>(*c, *p) : closed_wave_bytes<2>(*c, *p)) * WAVES_PER_BLOCK;
-    if (lds <= 64 * 1024 && p->launch_args) {
+  if (c->planner_mode == D2D_PLANNER_EXTERNAL && p->launch_args && (p->planner == D2D_PLAN_PRIMITIVE || p->gaze == D2D_GAZE_OXFORD)) {
+    // one persistent launch: every wave loops over the steps of its own env.  Specialisation as for the step kernel;
+    // as many envs (waves) per workgroup as the largest phase's LDS working set allows
+    const int spec = !spec_default_matches(*c) ? 0 : (c->N <= spec_ncap(1) ? 1 : (c->N <= spec_ncap(2) ? 2 : 3));
+    auto bytes = [&](int wpb) {
+      return spec == 0 ? closed_wave_bytes<0>(*c, *p, wpb) : spec == 1 ? closed_wave_bytes<1>(*c, *p, wpb)
+           : spec == 2 ? closed_wave_bytes<2>(*c, *p, wpb) : closed_wave_bytes<3>(*c, *p, wpb);
+    };
+    int wpb = (spec == 1 || spec == 2) ? WAVES_PER_BLOCK : pick_wpb(*c);
+    while (wpb >= 1 && (size_t)bytes(wpb) * wpb > 64 * 1024) wpb = (spec == 1 || spec == 2) ? 0 : wpb / 2;
+    if (wpb >= 1) {
+      const dim3 grid((c->B + wpb - 1) / wpb), block(WAVE * wpb);
+      const size_t lds = (size_t)bytes(wpb) * wpb;
       ClosedArgs *dev = (ClosedArgs *)p->launch_args;
       hipLaunchKernelGGL(k_closed_args, dim3(1), dim3(64), 0, (hipStream_t)stream, dev, *c, *s, *p, auto_reset ? *init : *s,
                          (int)on_done, (int)nsteps);
-      if (spec == 1) hipLaunchKernelGGL(k_closed<1>, grid, block, lds, (hipStream_t)stream, (const ClosedArgs *)dev);
-      else hipLaunchKernelGGL(k_closed<2>, grid, block, lds, (hipStream_t)stream, (const ClosedArgs *)dev);
+      switch (spec) {
+        case 0: hipLaunchKernelGGL(k_closed<0>, grid, block, lds, (hipStream_t)stream, (const ClosedArgs *)dev); break;
+        case 1: hipLaunchKernelGGL(k_closed<1>, grid, block, lds, (hipStream_t)stream, (const ClosedArgs *)dev); break;
+        case 2: hipLaunchKernelGGL(k_closed<2>, grid, block, lds, (hipStream_t)stream, (const ClosedArgs *)dev); break;
+        default: hipLaunchKernelGGL(k_closed<3>, grid, block, lds, (hipStream_t)stream, (const ClosedArgs *)dev); break;
+      }
       hipError_t err = hipGetLastError();
       if (err != hipSuccess) return fail(-3, hipGetErrorString(err));
       return 0;

@@ -622,7 +622,7 @@ __device__ __forceinline__ void plan_env(const d2d_cfg &c, const d2d_state &s, c
 __global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK) void k_plan(d2d_cfg c, d2d_state s, d2d_plan p, int skip_done) {
   const int lane = threadIdx.x & (WAVE - 1);
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);
-  const int e = blockIdx.x * WAVES_PER_BLOCK + wv;
+  const int e = blockIdx.x * (int)(blockDim.x / WAVE) + wv;
   if (e >= c.B) return;
   if (skip_done && s.flags[(size_t)e * 4 + D2D_F_DONE] != 0) return;
   plan_env(c, s, p, e, lane, d2d_lds + (size_t)wv * plan_wave_bytes(c.N, p.nu, p.n_sample, c.W * c.H));
@@ -971,7 +971,7 @@ __device__ __forceinline__ void gaze_env(const d2d_cfg &c, const d2d_state &s, c
 __global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK) void k_gaze(d2d_cfg c, d2d_state s, d2d_plan p, d2d_state init, int mode) {
   const int lane = threadIdx.x & (WAVE - 1);
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);
-  const int e = blockIdx.x * WAVES_PER_BLOCK + wv;
+  const int e = blockIdx.x * (int)(blockDim.x / WAVE) + wv;
   if (e >= c.B) return;
   if (mode == 2 && s.flags[(size_t)e * 4 + D2D_F_DONE] != 0) return;
   gaze_env(c, s, p, init, mode == 1, e, lane, d2d_lds + (size_t)wv * gaze_geom(c, p).wave_bytes);

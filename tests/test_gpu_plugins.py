@@ -78,6 +78,12 @@ CASES = [
     dict(B=6, T=40, chunk=5, agent_number=10, agent_radius=10, agent_max_speed=40, map_id=3,
          static_map='maps/obstacle_map.npy'),
     dict(B=5, T=60, chunk=10, agent_number=0, agent_radius=10, agent_max_speed=20, map_id=12, pillar_number=6),
+    # 172 agents (50 + the 122 of random_map_0): the any-N specialisation, two envs per workgroup
+    dict(B=4, T=30, chunk=6, agent_number=50, agent_radius=10, agent_max_speed=40, map_id=0, static_map='maps/random_map_0.npy',
+         init_pos=[250, 30]),
+    # a 1000 x 800 px map (100 x 80 cells), deeper and wider view: the generic instantiation of every phase
+    dict(B=4, T=60, chunk=12, agent_number=25, agent_radius=12, agent_max_speed=40, map_id=6, map_size=[1000, 800],
+         drone_view_depth=120, drone_view_range=120, init_pos=[300, 400], target_list=[[900, 700]]),
 ]
 
 
