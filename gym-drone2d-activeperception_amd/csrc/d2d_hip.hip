@@ -200,11 +200,10 @@ struct EnvRegs {  // lane-uniform per-env scalars carried in registers across th
 // Python / numpy `int(v // s)` for integer-valued s > 0: the exact mathematical floor.  floor(v * (1/s))
 // is within one of it; the fused remainder v - q s (exact when q is right) settles which.
 __device__ __forceinline__ int cell_fast(double v, double s, double inv_s) {
-  double q = floor(v * inv_s);
+  const double q = floor(v * inv_s);
   const double r = __builtin_fma(-q, s, v);
-  if (r < 0.0) q -= 1.0;
-  else if (r >= s) q += 1.0;
-  return (int)q;
+  // selects, not branches (ten of these sit in one collision test): at most one of the two corrections applies
+  return (int)q + ((r >= s) ? 1 : 0) - ((r < 0.0) ? 1 : 0);
 }
 
 // floor(v / s) for 0 < v < 2^24 and integer s >= 2: floor(v / s) == floor(floor(v) / s), and floor(v) fits

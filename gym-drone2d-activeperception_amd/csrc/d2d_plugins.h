@@ -38,17 +38,6 @@ __device__ __forceinline__ long long shfl_i64(long long v, int src) {
   return ((long long)hi << 32) | (unsigned int)lo;
 }
 
-// drone.map.get_grid (utils.py:545-548) on the explored map; NaN coordinates are refused before this is called.
-// The load is unconditional (clamped address) so that the five probes of one is_free() are in flight together.
-// DM: `const unsigned char *` in global memory, or the LDS copy the search stages (address-space inferred).
-template <typename DM>
-__device__ __forceinline__ bool dm_is_wall(const d2d_cfg &c, DM dm, double x, double y, double inv_scale) {
-  const bool oob = (x >= c.W_px || x < 0.0 || y >= c.H_px || y < 0.0);
-  const int ci = min(max(cell_fast(x, c.scale, inv_scale), 0), c.W - 1), cj = min(max(cell_fast(y, c.scale, inv_scale), 0), c.H - 1);
-  const unsigned char v = dm[ci * c.H + cj];
-  return oob | (v == D2D_OCCUPIED);
-}
-
 struct TrkView {  // active trackers of the env, compacted into LDS
   double *mx, *my, *vx, *vy;
   double *lim_plan, *lim_replan;  // norm(d) <= L rewritten as d.d <= T(L), see sq_threshold
@@ -70,17 +59,26 @@ __device__ __forceinline__ double sq_threshold(double L) {
   return t;
 }
 
-// Planner.is_free, traj_planner.py:28-59
+// Planner.is_free, traj_planner.py:28-59.  The five probes (x -+ d, y), (x, y), (x, y -+ d) of get_grid
+// (utils.py:545-548) share three column and three row indices; loads are unconditional (clamped) and in flight together.
 template <typename DM>
 __device__ __forceinline__ bool plan_is_free(const d2d_cfg &c, const d2d_plan &p, DM dm,
                                              const TrkView &T, double x, double y, double t, double inv_scale) {
   if (x != x || y != y) return false;
   const double d = p.safe_dist;
-  bool wall = dm_is_wall(c, dm, x - d, y, inv_scale);
-  wall = wall | dm_is_wall(c, dm, x, y, inv_scale);
-  wall = wall | dm_is_wall(c, dm, x + d, y, inv_scale);
-  wall = wall | dm_is_wall(c, dm, x, y - d, inv_scale);
-  wall = wall | dm_is_wall(c, dm, x, y + d, inv_scale);
+  const double xl = x - d, xr = x + d, yl = y - d, yr = y + d;
+  const int W1 = c.W - 1, H1 = c.H - 1;
+  const int i0 = min(max(cell_fast(xl, c.scale, inv_scale), 0), W1), i1 = min(max(cell_fast(x, c.scale, inv_scale), 0), W1),
+            i2 = min(max(cell_fast(xr, c.scale, inv_scale), 0), W1);
+  const int j0 = min(max(cell_fast(yl, c.scale, inv_scale), 0), H1), j1 = min(max(cell_fast(y, c.scale, inv_scale), 0), H1),
+            j2 = min(max(cell_fast(yr, c.scale, inv_scale), 0), H1);
+  const unsigned char v0 = dm[i0 * c.H + j1], v1 = dm[i1 * c.H + j1], v2 = dm[i2 * c.H + j1], v3 = dm[i1 * c.H + j0],
+                      v4 = dm[i1 * c.H + j2];
+  // out of the map = wall (get_grid): x >= W_px or x < 0 or y >= H_px or y < 0, per probe
+  const bool ox0 = (xl >= c.W_px) | (xl < 0.0), ox1 = (x >= c.W_px) | (x < 0.0), ox2 = (xr >= c.W_px) | (xr < 0.0);
+  const bool oy0 = (yl >= c.H_px) | (yl < 0.0), oy1 = (y >= c.H_px) | (y < 0.0), oy2 = (yr >= c.H_px) | (yr < 0.0);
+  const bool wall = (ox0 | oy1 | (v0 == D2D_OCCUPIED)) | (ox1 | oy1 | (v1 == D2D_OCCUPIED)) | (ox2 | oy1 | (v2 == D2D_OCCUPIED)) |
+                    (ox1 | oy0 | (v3 == D2D_OCCUPIED)) | (ox1 | oy2 | (v4 == D2D_OCCUPIED));
   bool hit = false;
   for (int q = 0; q < T.n; ++q) {
     const double ex = T.mx[q] + t * T.vx[q], ey = T.my[q] + t * T.vy[q];  // estimate_pos, utils.py:220-223
@@ -189,6 +187,10 @@ __device__ int plan_search(const d2d_cfg &c, const d2d_state &s, const d2d_plan 
     }
   }
   const double kInf = __longlong_as_double(0x7ff0000000000000ll);
+  // norm(v_end) < vmax  <=>  v.v <= (largest s with sqrt(s) < vmax)  -- sq_threshold of the double below vmax;
+  // norm(p - target) <= goal_tol  <=>  d.d <= sq_threshold(goal_tol): no square root per expansion
+  const double vmax2 = p.vmax > 0.0 ? sq_threshold(__longlong_as_double(__double_as_longlong(p.vmax) - 1)) : -1.0;
+  const double goal2 = sq_threshold(p.goal_tol);
   wave_sync_global();
   if (lane == 0) {
     const double x = dr[D2D_D_X], y = dr[D2D_D_Y], vx = dr[D2D_D_VX], vy = dr[D2D_D_VY];
@@ -215,7 +217,9 @@ __device__ int plan_search(const d2d_cfg &c, const d2d_state &s, const d2d_plan 
     (void)sp0; (void)sp1; (void)sp2; (void)sp3; (void)sp4; (void)sp5; (void)sp6; (void)sp7; (void)sp8;
     SP_T(sp0);
     // ---- min(open_set, key=total_cost): first minimal entry in insertion (= slot) order ----
-    double best = 0.0;
+    // Branch-free on purpose: with short-circuit conditions the compiler waits for every LDS read on its own.
+    // "no candidate" is (+inf, INT_MAX), so a plain lexicographic (cost, slot) compare needs no validity tests.
+    double best = kInf;
     int bidx = 0x7fffffff;
     {
       // the first D2D_SEARCH_LDS_NODES nodes from their LDS mirror (closed = +inf; an open node with an infinite or
@@ -224,17 +228,13 @@ __device__ int plan_search(const d2d_cfg &c, const d2d_state &s, const d2d_plan 
       for (int s0 = 0; s0 < nl; s0 += 4 * WAVE) {
         double t4[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int si = s0 + u * WAVE + lane;
-          t4[u] = si < nl ? S.tot[si] : kInf;
-        }
+        for (int u = 0; u < 4; ++u) t4[u] = S.tot[min(s0 + u * WAVE + lane, D2D_SEARCH_LDS_NODES - 1)];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const int si = s0 + u * WAVE + lane;
-          if (t4[u] < kInf && (bidx == 0x7fffffff || t4[u] < best)) {
-            best = t4[u];
-            bidx = si;
-          }
+          const bool take = (si < nl) & (t4[u] < best);  // ascending slots per lane: strict < keeps the earliest
+          best = take ? t4[u] : best;
+          bidx = take ? si : bidx;
         }
       }
       for (int s0 = nl; s0 < nn; s0 += WAVE) {  // beyond the mirror: state and cost fetched together
@@ -242,10 +242,9 @@ __device__ int plan_search(const d2d_cfg &c, const d2d_state &s, const d2d_plan 
         const int sc = min(si, nn - 1);
         const long long stt = nd.state[sc];
         const double t = nd.total[sc];
-        if (si < nn && stt == 1 && (bidx == 0x7fffffff || t < best)) {
-          best = t;
-          bidx = si;
-        }
+        const bool take = (si < nn) & (stt == 1) & (t < best);
+        best = take ? t : best;
+        bidx = take ? si : bidx;
       }
     }
     // lexicographic (cost, slot) minimum over the wave through LDS: 64 -> 8 -> 1, every lane ends with the winner
@@ -253,17 +252,21 @@ __device__ int plan_search(const d2d_cfg &c, const d2d_state &s, const d2d_plan 
     S.ri[lane] = bidx;
     wave_sync_lds();
     {
+      double v8[8];
+      int i8[8];
       const int g0 = (lane & 7) * 8;
-      double b = S.rv[g0];
-      int bi = S.ri[g0];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        v8[k] = S.rv[g0 + k];
+        i8[k] = S.ri[g0 + k];
+      }
+      double b = v8[0];
+      int bi = i8[0];
 #pragma unroll
       for (int k = 1; k < 8; ++k) {
-        const double t2 = S.rv[g0 + k];
-        const int i2 = S.ri[g0 + k];
-        if (i2 != 0x7fffffff && (bi == 0x7fffffff || t2 < b || (t2 == b && i2 < bi))) {
-          b = t2;
-          bi = i2;
-        }
+        const bool take = (v8[k] < b) | ((v8[k] == b) & (i8[k] < bi));
+        b = take ? v8[k] : b;
+        bi = take ? i8[k] : bi;
       }
       wave_sync_lds();
       if (lane < 8) {
@@ -271,16 +274,18 @@ __device__ int plan_search(const d2d_cfg &c, const d2d_state &s, const d2d_plan 
         S.ri[lane] = bi;
       }
       wave_sync_lds();
-      b = S.rv[0];
-      bi = S.ri[0];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        v8[k] = S.rv[k];
+        i8[k] = S.ri[k];
+      }
+      b = v8[0];
+      bi = i8[0];
 #pragma unroll
       for (int k = 1; k < 8; ++k) {
-        const double t2 = S.rv[k];
-        const int i2 = S.ri[k];
-        if (i2 != 0x7fffffff && (bi == 0x7fffffff || t2 < b || (t2 == b && i2 < bi))) {
-          b = t2;
-          bi = i2;
-        }
+        const bool take = (v8[k] < b) | ((v8[k] == b) & (i8[k] < bi));
+        b = take ? v8[k] : b;
+        bi = take ? i8[k] : bi;
       }
       bidx = bi;
       wave_sync_lds();
@@ -302,7 +307,7 @@ __device__ int plan_search(const d2d_cfg &c, const d2d_state &s, const d2d_plan 
     const int citr = nd.link[cur].y;
     SP_T(sp2);
     SP_ADD(1, sp1, sp2);
-    if (norm2(px - tx, py - ty) <= p.goal_tol) {  // :158
+    if (__builtin_fma(py - ty, py - ty, (px - tx) * (px - tx)) <= goal2) {  // :158
       goal = cur;
       break;
     }
@@ -320,7 +325,7 @@ __device__ int plan_search(const d2d_cfg &c, const d2d_state &s, const d2d_plan 
       const double ax = S.us[ia], ay = S.us[ja];
       const double hx = ax / 2, hy = ay / 2;
       const double vex = vx + (2 * H) * hx, vey = vy + (2 * H) * hy;  // :172,183
-      ok = ok && (norm2(vex, vey) < p.vmax);
+      ok = ok && (__builtin_fma(vey, vey, vex * vex) <= vmax2);
       // :175-180.  Few primitives pass the speed limit (about ten of 64), so the collision samples are spread over
       // the lanes as (primitive, sample) pairs instead of one sample round per iteration: the reference's early
       // `break` only skips work, a successor needs ALL its samples free.
@@ -385,27 +390,38 @@ __device__ int plan_search(const d2d_cfg &c, const d2d_state &s, const d2d_plan 
         S.ri[rank] = lane;
       }
       wave_sync_lds();
-      int leader = lane, wlane = -1;
-      double wcost = 0.0;
-      for (int j0 = 0; j0 < nok; j0 += 8) {  // eight entries at a time: their LDS reads are in flight together
+      int leader = lane, wlane = lane;
+      double wcost = cost;
+      bool dup = false;
+      for (int j0 = 0; j0 < nok; j0 += 8) {  // keys only, eight at a time: repeats within one expansion are rare
         long long k8[8];
-        double c8[8];
-        int l8[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int j = min(j0 + u, nok - 1);
-          k8[u] = S.rk[j];
-          c8[u] = S.rv[j];
-          l8[u] = S.ri[j];
-        }
+        for (int u = 0; u < 8; ++u) k8[u] = S.rk[min(j0 + u, nok - 1)];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          if (ok && j0 + u < nok && k8[u] == key) {
-            if (l8[u] < leader) leader = l8[u];
-            if (wlane < 0 || c8[u] < wcost) {
-              wcost = c8[u];
-              wlane = l8[u];
-            }
+        for (int u = 0; u < 8; ++u) dup = dup | (ok & (j0 + u < nok) & (j0 + u != rank) & (k8[u] == key));
+      }
+      if (__any(dup)) {
+        leader = lane;
+        wlane = -1;
+        wcost = 0.0;
+        for (int j0 = 0; j0 < nok; j0 += 8) {  // eight entries at a time: their LDS reads are in flight together
+          long long k8[8];
+          double c8[8];
+          int l8[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int j = min(j0 + u, nok - 1);
+            k8[u] = S.rk[j];
+            c8[u] = S.rv[j];
+            l8[u] = S.ri[j];
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {  // selects only: a branch per entry would wait for every LDS read on its own
+            const bool same = ok & (j0 + u < nok) & (k8[u] == key);
+            leader = (same & (l8[u] < leader)) ? l8[u] : leader;
+            const bool better = same & ((wlane < 0) | (c8[u] < wcost));
+            wcost = better ? c8[u] : wcost;
+            wlane = better ? l8[u] : wlane;
           }
         }
       }
