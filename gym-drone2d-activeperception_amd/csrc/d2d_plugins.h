@@ -400,29 +400,19 @@ __device__ int plan_search(const d2d_cfg &c, const d2d_state &s, const d2d_plan 
 #pragma unroll
         for (int u = 0; u < 8; ++u) dup = dup | (ok & (j0 + u < nok) & (j0 + u != rank) & (k8[u] == key));
       }
-      if (__any(dup)) {
+      if (__any(dup)) {  // rare: a plain loop keeps the register pressure of the common path low
         leader = lane;
         wlane = -1;
         wcost = 0.0;
-        for (int j0 = 0; j0 < nok; j0 += 8) {  // eight entries at a time: their LDS reads are in flight together
-          long long k8[8];
-          double c8[8];
-          int l8[8];
-#pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            const int j = min(j0 + u, nok - 1);
-            k8[u] = S.rk[j];
-            c8[u] = S.rv[j];
-            l8[u] = S.ri[j];
-          }
-#pragma unroll
-          for (int u = 0; u < 8; ++u) {  // selects only: a branch per entry would wait for every LDS read on its own
-            const bool same = ok & (j0 + u < nok) & (k8[u] == key);
-            leader = (same & (l8[u] < leader)) ? l8[u] : leader;
-            const bool better = same & ((wlane < 0) | (c8[u] < wcost));
-            wcost = better ? c8[u] : wcost;
-            wlane = better ? l8[u] : wlane;
-          }
+#pragma unroll 1
+        for (int j = 0; j < nok; ++j) {
+          const bool same = ok & (S.rk[j] == key);
+          const int lj = S.ri[j];
+          const double cj = S.rv[j];
+          leader = (same & (lj < leader)) ? lj : leader;
+          const bool better = same & ((wlane < 0) | (cj < wcost));
+          wcost = better ? cj : wcost;
+          wlane = better ? lj : wlane;
         }
       }
       wave_sync_lds();
