@@ -701,7 +701,8 @@ __host__ __device__ inline GazeGeom gaze_geom(const d2d_cfg &c, const d2d_plan &
   g.bbn = 2 * ((int)(c.depth / c.scale) + 1) + 3;
   g.ncell = g.bbn * g.bbn;
   // int swept index + double reward + candidate bits per box cell, block sums + add stacks per candidate, the plan
-  const int bytes = 4 * g.ncell + 8 * g.ncell + ((g.ncell + 7) & ~7) + 8 * p.n_yaw * (2 * p.pw_nleaf - 1) + 8 * 16 +
+  const int sums = 8 * p.n_yaw * (2 * p.pw_nleaf - 1), live = 4 * g.ncell;  // the live-cell list shares the sums' space
+  const int bytes = 4 * g.ncell + 8 * g.ncell + ((g.ncell + 7) & ~7) + (((sums > live ? sums : live) + 7) & ~7) + 8 * 16 +
                     4 * (2 * p.pw_nleaf + p.pw_ntree);
   g.wave_bytes = (bytes + 15) & ~15;
   return g;
@@ -725,8 +726,10 @@ __device__ __forceinline__ void gaze_env(const d2d_cfg &c, const d2d_state &s, c
   double *rew = (double *)base;                                   // [ncell]
   const int nnode = 2 * p.pw_nleaf - 1;                           // blocks + their pairwise sums up to the root
   double *lsum = rew + g.ncell;                                   // [n_yaw][nnode]
-  double *stk = lsum + p.n_yaw * nnode;                           // [8][2] view directions
+  const int lsum_doubles = max(p.n_yaw * nnode, (g.ncell + 1) / 2);
+  double *stk = lsum + lsum_doubles;                              // [8][2] view directions
   int *swi = (int *)(stk + 16);                                   // [ncell]
+  int *swl = (int *)lsum;                                         // [ncell] the live cells of the box: done before the sums start
   int *pwl = swi + g.ncell;                                       // [pw_nleaf][2] + [pw_ntree]: the pairwise plan
   int *pwp = pwl + 2 * p.pw_nleaf;
   unsigned char *cm = (unsigned char *)(pwp + p.pw_ntree);        // [ncell]
@@ -810,66 +813,81 @@ __device__ __forceinline__ void gaze_env(const d2d_cfg &c, const d2d_state &s, c
     }
   }
   wave_sync_global();  // LDS hand-off of the swept map AND the seen map the lanes wrote above
-  // ---- reward (:109-111) and the candidates' view bits for every box cell; eight cells per lane and pass, their
-  //      seen-map entries fetched together, then their table rows, then the arithmetic ----
-  for (int q0 = 0; q0 < g.ncell; q0 += 8 * WAVE) {
-    int sn[8];
-    bool in[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int q = q0 + u * WAVE + lane;
-      int r, cc;
-      fdb.divmod(q, r, cc);
-      const int i = bi + r, j = bj + cc;
-      in[u] = q < g.ncell && i >= 0 && i < W && j >= 0 && j < H;
-      sn[u] = seen[min(max(i, 0), W - 1) * H + min(max(j, 0), H - 1)];
+  // ---- reward (:109-111) and the candidates' view bits.  Only box cells inside the map AND inside the view disk of
+  //      the head (d2 <= depth^2, about half of the box) can carry a view bit; every other cell contributes 0 to all
+  //      six sums whatever its reward.  Those live cells are compacted first (ballot + prefix count into the `swl`
+  //      list), so the expensive part runs on ~4 full passes instead of 7 sparse ones ----
+  int nlive = 0;
+  for (int q0 = 0; q0 < g.ncell; q0 += WAVE) {
+    const int q = q0 + lane;
+    int r, cc;
+    fdb.divmod(q, r, cc);
+    const int i = bi + r, j = bj + cc;
+    bool live = false;
+    if (q < g.ncell) {
+      const double ca = hx - (double)i * c.scale, cb = hy - (double)j * c.scale;
+      live = (i >= 0) & (i < W) & (j >= 0) & (j < H) & (ca * ca + cb * cb <= depth2);
+      rew[q] = 0.0;
+      cm[q] = 0;
     }
-    double tobs[8];
+    const unsigned long long lm = __ballot(live);
+    if (live) swl[nlive + __popcll(lm & ((1ull << lane) - 1ull))] = q;
+    nlive += __popcll(lm);
+  }
+  wave_sync_lds();
+  for (int l0 = 0; l0 < nlive; l0 += 4 * WAVE) {
+    // four live cells per lane: their seen-map entries are fetched together, then their table rows, then the arithmetic
+    int qq[4], sn[4];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) tobs[u] = sn[u] > 0 ? p.tobs_tab[call - min(sn[u], call)] : p.tobs_tab[p.tobs_len + call];
+    for (int u = 0; u < 4; ++u) {
+      qq[u] = swl[min(l0 + u * WAVE + lane, nlive - 1)];
+      int r, cc;
+      fdb.divmod(qq[u], r, cc);
+      sn[u] = seen[(bi + r) * H + (bj + cc)];
+    }
+    double tobs[4];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int q = q0 + u * WAVE + lane;
-      if (q < g.ncell) {
-        double rw = 0.0;
-        unsigned int bits = 0;
-        if (in[u]) {
-          int r, cc;
-          fdb.divmod(q, r, cc);
-          const int i = bi + r, j = bj + cc;
-          const int si = swi[q];
-          const double sw = si >= 0 ? (double)si * c.dt : 0.0;
-          if (sw > 0.0 && sw <= 3.0 && tobs[u] >= 0.5) rw = 1000000.0;
-          else if (sw > 3.0 && tobs[u] >= 0.5) rw = 1000.0;
-          else rw = (1.0 * tobs[u] < 1.0) ? 1.0 * tobs[u] : 1.0;
-          // the six candidates look from the same point: distance terms once per cell, direction terms per candidate
-          const double x = (double)i * c.scale, y = (double)j * c.scale;
-          const double ca = hx - x, cb = hy - y;
-          const double d2 = ca * ca + cb * cb;
-          if (d2 <= 0.0) {
-            bits = (1u << p.n_yaw) - 1u;
-          } else if (d2 <= depth2) {
-            const double dxv = x - hx, dyv = y - hy;
-            const double rhs = quick * d2, hi = rhs * (1.0 + 1e-12), lo = rhs * (1.0 - 1e-12), top = d2 * (1.0 - 1e-12);
-            double rs = 0.0;
-            bool have_rs = false;
+    for (int u = 0; u < 4; ++u) tobs[u] = sn[u] > 0 ? p.tobs_tab[call - min(sn[u], call)] : p.tobs_tab[p.tobs_len + call];
 #pragma unroll
-            for (int a = 0; a < 7; ++a) {
-              if (a < p.n_yaw) {
-                const double dot = dxv * cone[a].cy + dyv * cone[a].sy;
-                const double lhs = dot * dot;
-                bool in_cone;
-                if (quick > 0.0 && dot > 0.0 && lhs > hi && lhs < top) in_cone = true;
-                else if (quick > 0.0 && (dot <= 0.0 || lhs < lo)) in_cone = false;
-                else {
-                  if (!have_rs) {
-                    rs = sqrt(d2);
-                    have_rs = true;
-                  }
-                  in_cone = acos_le(p, dot / rs);
-                }
-                bits |= in_cone ? (1u << a) : 0u;
-              }
+    for (int u = 0; u < 4; ++u) {
+      if (l0 + u * WAVE + lane < nlive) {
+        const int q = qq[u];
+        int r, cc;
+        fdb.divmod(q, r, cc);
+        const int i = bi + r, j = bj + cc;
+        const int si = swi[q];
+        const double sw = si >= 0 ? (double)si * c.dt : 0.0;
+        const bool stale = tobs[u] >= 0.5;
+        double rw = (1.0 * tobs[u] < 1.0) ? 1.0 * tobs[u] : 1.0;  // np.clip(c3 * t, -inf, 1)
+        rw = ((sw > 3.0) & stale) ? 1000.0 : rw;
+        rw = ((sw > 0.0) & (sw <= 3.0) & stale) ? 1000000.0 : rw;
+        // the six candidates look from the same point: distance terms once per cell, direction terms per candidate
+        const double x = (double)i * c.scale, y = (double)j * c.scale;
+        const double ca = hx - x, cb = hy - y;
+        const double d2 = ca * ca + cb * cb;
+        unsigned int bits = 0, rare = 0;
+        if (d2 <= 0.0) {
+          bits = (1u << p.n_yaw) - 1u;
+        } else {
+          const double dxv = x - hx, dyv = y - hy;
+          const double rhs = quick * d2, hi = rhs * (1.0 + 1e-12), lo = rhs * (1.0 - 1e-12), top = d2 * (1.0 - 1e-12);
+#pragma unroll
+          for (int a = 0; a < 7; ++a) {
+            if (a < p.n_yaw) {
+              const double dot = dxv * cone[a].cy + dyv * cone[a].sy;
+              const double lhs = dot * dot;
+              const bool inside = (quick > 0.0) & (dot > 0.0) & (lhs > hi) & (lhs < top);
+              const bool outside = (quick > 0.0) & ((dot <= 0.0) | (lhs < lo));
+              bits |= inside ? (1u << a) : 0u;
+              rare |= (inside | outside) ? 0u : (1u << a);
+            }
+          }
+          if (rare) {  // within 1e-12 of a cone's edge or axis (or a cone the shortcut does not cover): the literal test
+            const double rs = sqrt(d2);
+            for (unsigned int m = rare; m; m &= m - 1) {
+              const int a = __ffs((int)m) - 1;
+              const double dot = dxv * vdir[2 * a] + dyv * vdir[2 * a + 1];
+              bits |= acos_le(p, dot / rs) ? (1u << a) : 0u;
             }
           }
         }
