@@ -18,6 +18,8 @@
 //   stores   agents, drone map, grid, trackers, flags, observation
 // What bounds the kernel is instruction issue (~2000 VALU + ~1500 SALU wave-instructions per env-step, fp64
 // heavy) and SGPR pressure, not bytes: see DESIGN.md section 3 for the measurements behind each choice.
+// The planner / gaze plugins (d2d_plugins.h) and the persistent closed loop k_closed (every wave loops over the steps
+// of its own env: gaze -> perceive -> plan -> act) follow the step kernel below.
 // There is no dense contraction on this path, hence no MFMA.  Arithmetic is fp64 in the reference's
 // own operation order (compiled with -ffp-contract=off; the few fused multiply-adds are the ones the
 // reference's runtime performs: libm tan, OpenBLAS dgemv), which is what makes the integer outputs

@@ -7,14 +7,22 @@
 // Mapping: ONE WAVEFRONT PER ENV, like the fused step: envs never talk to each other, every hand-off is lane ->
 // lane inside one wave (LDS, or the env's own global scratch behind wave_sync_global()).
 //   search            lane = motion primitive (8 x 8 accelerations = one wave); the open set is an append-only node
-//                     array in the env's scratch (Python dict order = insertion order = slot order), min() is a
-//                     strided scan + lexicographic wave reduction, the dict lookup an open-addressing hash table;
-//                     the successors of one expansion are de-duplicated among the lanes with ballot / readlane and
+//                     array in the env's scratch (Python dict order = insertion order = slot order) with the costs of
+//                     the first 512 nodes mirrored in LDS (closed = +inf): min() is a scan of that mirror + a
+//                     lexicographic (cost, slot) reduction 64 -> 8 -> 1 through LDS; the dict lookup is an
+//                     open-addressing hash table; the (primitive, collision sample) pairs of the few primitives that
+//                     pass the speed limit are spread over the lanes, their probes read an LDS copy of the explored
+//                     map; the successors of one expansion are de-duplicated among the lanes (ballot + LDS) and
 //                     inserted together, which gives the same final dict as the reference's one-by-one loop
 //   replan_check      lane = trajectory waypoint, __any over the wave
-//   view maps         lane = cell of the 2 * depth bounding box around the viewpoint (cells outside cannot be seen)
-//   np.sum            numpy's pairwise order: lane = (candidate, accumulator 0..7) walks one <= 128-element block,
-//                     ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) by three shuffles, blocks added by the host's program
+//   view maps         lane = cell of the 2 * depth bounding box around the viewpoint (cells outside cannot be seen);
+//                     for the six candidates only the cells inside the map and the view disk, compacted by ballot
+//   np.sum            numpy's pairwise order: lane = (candidate, accumulator 0..7) walks the box cells of one
+//                     <= 128-element block, ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) by three shuffles, the blocks'
+//                     sums added level by level of the recursion tree (host table pw_tree)
+// What bounds both stages is a chain of short dependent steps of ONE wave, so the code is written
+// for latency: loads issued together before their first use, selects instead of short-circuit conditions (a branch
+// per LDS read makes the wave wait for every read on its own), constant tables staged in LDS.
 // Arithmetic is fp64 in the reference's operation order with numpy's measured roundings (oracle/d2d_oracle.c lists
 // them); sin / cos are csrc/d2d_sincos.h, arccos(q) <= half_fov is the host's decision window.
 
@@ -29,13 +37,6 @@ __device__ __forceinline__ double shfl_f64(double v, int src) {
   lo = __shfl(lo, src, WAVE);
   hi = __shfl(hi, src, WAVE);
   return __hiloint2double(hi, lo);
-}
-
-__device__ __forceinline__ long long shfl_i64(long long v, int src) {
-  int lo = (int)(v & 0xffffffffll), hi = (int)(v >> 32);
-  lo = __shfl(lo, src, WAVE);
-  hi = __shfl(hi, src, WAVE);
-  return ((long long)hi << 32) | (unsigned int)lo;
 }
 
 struct TrkView {  // active trackers of the env, compacted into LDS

@@ -242,7 +242,8 @@ typedef struct d2d_plan {
   uint8_t *trk_prev;    /* [B][N] tracker.active as the planner stage last saw it (detects the archive) */
   int32_t *seen_step;   /* [B][W][H] Oxford: number of the plan() call that last saw the cell, 0 = never */
   /* ---- scratch of the search (contents meaningless between calls) ---- */
-  double *nodes;        /* [B][node_cap][D2D_NODE_F] */
+  double *nodes;        /* [B][node_cap * D2D_NODE_F] search nodes; the field order inside an env's block is the
+                           implementation's (the oracle keeps records, the HIP library planes) */
   int32_t *hash;        /* [B][hash_cap] */
   void *launch_args;    /* >= D2D_LAUNCH_ARGS_BYTES of device memory where the persistent closed-loop launch parks its
                            arguments (NULL: d2d_closed_loop launches every stage of every step separately) */
@@ -251,7 +252,8 @@ typedef struct d2d_plan {
                            capacity overflow flag (sticky; a search that overflowed reports failure) */
 } d2d_plan;
 
-/* one search node: position(2), velocity(2), cost, total_cost, acc(2), then parent slot / itr / key as raw bits */
+/* one search node = D2D_NODE_F doubles: position(2), velocity(2), cost, total_cost, acc(2), then parent slot / itr /
+ * key / state as raw bits (record offsets of the oracle; scratch, never exchanged between implementations) */
 #define D2D_NODE_F 12
 #define D2D_LAUNCH_ARGS_BYTES 2048
 #define D2D_N_PX 0
