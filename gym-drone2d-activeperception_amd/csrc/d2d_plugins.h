@@ -745,7 +745,7 @@ __device__ __forceinline__ void gaze_env(const d2d_cfg &c, const d2d_state &s, c
   const int head = hdr[0], n = hdr[1] - hdr[0];
   int *__restrict__ seen = p.seen_step + (size_t)e * W * H;
   double *act = (double *)s.action;
-  if (call >= p.tobs_len) {  // refused by the host before the launch; never index past the table
+  if (call >= p.tobs_len) {  // stepping past the longest episode (D2D_DONE_CONTINUE): the table ends, the yaw is held
     if (lane == 0) act[e] = 0.0;
     return;
   }

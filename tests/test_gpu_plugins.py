@@ -128,6 +128,17 @@ def test_freeze_mode_matches_oracle(pkg, hip, oracle, kw):
     assert int(steps[done].max()) < 240          # they stopped where their episode ended
 
 
+def test_continue_mode_past_the_longest_episode(pkg, hip, oracle):
+    """D2D_DONE_CONTINUE keeps stepping finished envs, also past max_flight_time (where Oxford's time table ends and
+    the policy holds the yaw): device == oracle throughout."""
+    dev, ref = _pair(pkg, hip, oracle, 6, agent_number=8, agent_radius=10, agent_max_speed=20, map_id=55, max_flight_time=3)
+    for _ in range(5):
+        dev.closed_loop(12)
+        ref.closed_loop(12)
+        _assert_same(dev, ref, 'continue')
+    assert int(ref.state.counters[:, pkg._abi.C_STEPS].min()) == 60
+
+
 def test_full_size_closed_loop_properties(pkg, hip):
     """BASELINE config 2 with the plugins on the device: 4096 envs, Oxford + Primitive.  Size-independent properties:
     copies of one world stay identical, actions are yaw-rate candidates, trajectories are consistent."""
