@@ -603,7 +603,12 @@ __device__ __forceinline__ void plan_env(const d2d_cfg &c, const d2d_state &s, c
   int ok = 1;
   if (stored - head == 0) {
     head = 0;
+    // A search is a long chain of short dependent steps and, in the persistent loop, what the slowest env of a launch
+    // spends its time on; its wave shares the SIMD with three others that mostly run throughput phases.  Raised issue
+    // priority lets it go first whenever it is ready (0.78 ms -> its stand-alone 0.46 ms is the range at stake).
+    __builtin_amdgcn_s_setprio(3);
     stored = plan_search(c, s, p, e, lane, T, S, dm, inv_scale);
+    __builtin_amdgcn_s_setprio(0);
     ok = stored > 0 ? 1 : 0;
     wave_sync_global();
   }
