@@ -709,7 +709,7 @@ __host__ __device__ inline GazeGeom gaze_geom(const d2d_cfg &c, const d2d_plan &
   // int swept index + double reward + candidate bits per box cell, block sums + add stacks per candidate, the plan
   const int sums = 8 * p.n_yaw * (2 * p.pw_nleaf - 1), live = 4 * g.ncell;  // the live-cell list shares the sums' space
   const int bytes = 4 * g.ncell + 8 * g.ncell + ((g.ncell + 7) & ~7) + (((sums > live ? sums : live) + 7) & ~7) + 8 * 16 +
-                    4 * (2 * p.pw_nleaf + p.pw_ntree);
+                    4 * (4 * p.pw_nleaf + p.pw_ntree);
   g.wave_bytes = (bytes + 15) & ~15;
   return g;
 }
@@ -736,8 +736,8 @@ __device__ __forceinline__ void gaze_env(const d2d_cfg &c, const d2d_state &s, c
   double *stk = lsum + lsum_doubles;                              // [8][2] view directions
   int *swi = (int *)(stk + 16);                                   // [ncell]
   int *swl = (int *)lsum;                                         // [ncell] the live cells of the box: done before the sums start
-  int *pwl = swi + g.ncell;                                       // [pw_nleaf][2] + [pw_ntree]: the pairwise plan
-  int *pwp = pwl + 2 * p.pw_nleaf;
+  int *pwl = swi + g.ncell;                                       // [pw_nleaf][4] + [pw_ntree]: the pairwise plan
+  int *pwp = pwl + 4 * p.pw_nleaf;
   unsigned char *cm = (unsigned char *)(pwp + p.pw_ntree);        // [ncell]
   const int W = c.W, H = c.H;
   const double deg2rad = 0x1.1df46a2529d39p-6;                    // math.radians
@@ -755,7 +755,7 @@ __device__ __forceinline__ void gaze_env(const d2d_cfg &c, const d2d_state &s, c
     return;
   }
   // the pairwise plan (a few hundred bytes) into LDS with one coalesced read; used only after several barriers
-  for (int k = lane; k < 2 * p.pw_nleaf; k += WAVE) pwl[k] = p.pw_leaf[k];
+  for (int k = lane; k < 4 * p.pw_nleaf; k += WAVE) pwl[k] = p.pw_leaf[k];
   for (int k = lane; k < p.pw_ntree; k += WAVE) pwp[k] = p.pw_tree[k];
   const FastDiv fdb(g.bbn);
   // shortcut of view_cell: only for cones narrower than 180 degrees whose edge is well inside (0, 1); cos(half_fov)
@@ -913,17 +913,13 @@ __device__ __forceinline__ void gaze_env(const d2d_cfg &c, const d2d_state &s, c
   const int row_lo = min(max(bi, 0), W - 1), row_hi = min(max(bi + g.bbn - 1, 0), W - 1);
   const int lf_lo = p.pw_rowleaf[row_lo];
   int lf_hi = p.pw_rowleaf[row_hi];
-  while (lf_hi + 1 < p.pw_nleaf && pwl[2 * (lf_hi + 1)] < (row_hi + 1) * H) ++lf_hi;  // the row's last cell may sit further on
+  while (lf_hi + 1 < p.pw_nleaf && pwl[4 * (lf_hi + 1)] < (row_hi + 1) * H) ++lf_hi;  // the row's last cell may sit further on
   for (int k = lane; k < p.n_yaw * p.pw_nleaf; k += WAVE) {
     const int a = k / p.pw_nleaf, lf = k - a * p.pw_nleaf;
     if (lf < lf_lo || lf > lf_hi) lsum[a * nnode + lf] = 0.0;
   }
   for (int lf = lf_lo; lf <= lf_hi; ++lf) {
-    const int off = pwl[2 * lf], m = pwl[2 * lf + 1];
-    // rows of the box this block can touch at all
-    int i_first, i_last, dummy;
-    fdh.divmod(off, i_first, dummy);
-    fdh.divmod(off + m - 1, i_last, dummy);
+    const int off = pwl[4 * lf], m = pwl[4 * lf + 1], i_first = pwl[4 * lf + 2], i_last = pwl[4 * lf + 3];  // rows it covers
     double res = 0.0;
     if (i_last >= bi && i_first < bi + g.bbn && jlo < jhi) {
       if (m < 8) {

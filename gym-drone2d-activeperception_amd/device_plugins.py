@@ -179,7 +179,9 @@ def build_tables(params, cfg):
     t['tobs_tab'] = tab
     leaves, prog = pairwise_plan(cfg.W * cfg.H)
     ops, lvl_start, root = pairwise_levels(len(leaves), prog)
-    t['pw_leaf'], t['pw_prog'] = leaves, prog
+    # per block: offset, length, first and last grid row it covers (the device walks rows)
+    t['pw_leaf'] = np.array([[o, m, o // cfg.H, (o + m - 1) // cfg.H] for o, m in leaves], dtype=np.int32).reshape(-1, 4)
+    t['pw_prog'] = prog
     # the same additions level by level: [n_levels, root, level_start[0..n_levels], then (dst, left, right) per op]
     t['pw_tree'] = np.concatenate([[len(lvl_start) - 1, root], lvl_start, ops.ravel()]).astype(np.int32)
     # first block of every grid row (the blocks a view box can touch are a contiguous range)

@@ -188,7 +188,7 @@ typedef struct d2d_state {
  *   tobs_tab  [2][tobs_len]   row 0: 0 + dt + dt + ... (k additions), row 1: 5 + dt + dt + ...: the value of a
  *                             cell of Oxford.last_time_observed_map k calls after it was last seen / if it never
  *                             was (yaw_planner.py:48,95-97); the map itself is kept as `seen_step`
- *   pw_leaf   [pw_nleaf][2]   offset, length of the <= 128-element blocks numpy's pairwise summation cuts a
+ *   pw_leaf   [pw_nleaf][4]   offset, length, first row, last row of the <= 128-element blocks numpy's pairwise summation cuts a
  *   pw_prog   [pw_nprog]      W * H array into, and the order their partial sums are added in (>= 0: push
  *                             block, -1: add the two on top) -- np.sum(view * reward), yaw_planner.py:123.
  *                             pw_tree holds the same additions grouped by tree level (independent within a

@@ -937,7 +937,7 @@ static double pw_sum(const d2d_plan *p, const double *a) {
   int sp = 0;
   for (int k = 0; k < p->pw_nprog; ++k) {
     int op = p->pw_prog[k];
-    if (op >= 0) st[sp++] = pw_leaf_sum(a + p->pw_leaf[2 * op], p->pw_leaf[2 * op + 1]);
+    if (op >= 0) st[sp++] = pw_leaf_sum(a + p->pw_leaf[4 * op], p->pw_leaf[4 * op + 1]);
     else {
       sp -= 1;
       st[sp - 1] = st[sp - 1] + st[sp];

@@ -49,6 +49,7 @@ def test_pairwise_plan_is_numpy_sum(pkg):
     for W, H in ((50, 50), (64, 37), (100, 80), (9, 9), (90, 90)):
         leaves, prog = DP.pairwise_plan(W * H)
         assert len(prog) == 2 * len(leaves) - 1 and all(l[0] % 8 == 0 for l in leaves)
+        assert leaves[0][0] == 0 and all(leaves[k][0] + leaves[k][1] == leaves[k + 1][0] for k in range(len(leaves) - 1))
         ops, start, root = DP.pairwise_levels(len(leaves), prog)
         assert len(ops) == len(leaves) - 1 and start[-1] == len(ops) and root == (2 * len(leaves) - 2 if len(leaves) > 1 else 0)
         done = set(range(len(leaves)))
