@@ -1516,6 +1516,8 @@ int plan_check(const d2d_cfg *c, const d2d_state *s, const d2d_plan *p) {
     if (p->pw_nleaf <= 0 || p->pw_nprog != 2 * p->pw_nleaf - 1 || p->pw_ntree < 3) return fail(-1, "gaze: bad pairwise-sum program");
     if ((size_t)gaze_geom(*c, *p).wave_bytes > 64 * 1024)
       return fail(-4, "gaze: map / view depth too large for the per-env LDS working set");
+    if (gaze_geom(*c, *p).bbn > 64 || c->W * c->H < 64)
+      return fail(-4, "gaze: view depth above 29 cells or a map below 64 cells");
     if (c->max_steps + 2 > (double)p->tobs_len) return fail(-1, "gaze: tobs_tab shorter than the longest episode");
   }
   return 0;

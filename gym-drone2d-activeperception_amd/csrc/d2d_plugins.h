@@ -799,6 +799,10 @@ __device__ __forceinline__ void gaze_env(const d2d_cfg &c, const d2d_state &s, c
       }
     }
   }
+#if defined(D2D_GAZE_ABL) && D2D_GAZE_ABL == 1
+  if (lane == 0) act[e] = 0.0;
+  return;
+#endif
   if (n == 0) {  // :118-119
     if (lane == 0) act[e] = 0.0;
     return;
@@ -819,6 +823,10 @@ __device__ __forceinline__ void gaze_env(const d2d_cfg &c, const d2d_state &s, c
     }
   }
   wave_sync_global();  // LDS hand-off of the swept map AND the seen map the lanes wrote above
+#if defined(D2D_GAZE_ABL) && D2D_GAZE_ABL == 2
+  if (lane == 0) act[e] = 0.0;
+  return;
+#endif
   // ---- reward (:109-111) and the candidates' view bits.  Only box cells inside the map AND inside the view disk of
   //      the head (d2 <= depth^2, about half of the box) can carry a view bit; every other cell contributes 0 to all
   //      six sums whatever its reward.  Those live cells are compacted first (ballot + prefix count into the `swl`
@@ -841,6 +849,10 @@ __device__ __forceinline__ void gaze_env(const d2d_cfg &c, const d2d_state &s, c
     nlive += __popcll(lm);
   }
   wave_sync_lds();
+#if defined(D2D_GAZE_ABL) && D2D_GAZE_ABL == 3
+  if (lane == 0) act[e] = 0.0;
+  return;
+#endif
   for (int l0 = 0; l0 < nlive; l0 += 4 * WAVE) {
     // four live cells per lane: their seen-map entries are fetched together, then their table rows, then the arithmetic
     int qq[4], sn[4];
@@ -903,67 +915,84 @@ __device__ __forceinline__ void gaze_env(const d2d_cfg &c, const d2d_state &s, c
     }
   }
   wave_sync_lds();
+#if defined(D2D_GAZE_ABL) && D2D_GAZE_ABL == 4
+  if (lane == 0) act[e] = 0.0;
+  return;
+#endif
   // ---- np.sum(view * reward) per candidate in numpy's pairwise order (:123) ----
-  // lane = (candidate a, accumulator r): block by block, elements off + r + 8 k; cells outside the box contribute 0
-  const int a_of = lane >> 3, r_of = lane & 7;
+  // lane = one accumulator chain (block, r) of the blocks the box touches, carrying the partial sums of ALL six
+  // candidates: the chain's elements off + r + 8 k that lie in the box (at most ~12 at the default geometry: a block spans
+  // <= 4 grid rows, a box row holds <= 3 cells of a residue) are read once (view bits + reward) and added to the candidates whose bit
+  // is set.  The eight chains of a block are eight neighbouring lanes: ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) by three
+  // shuffles per candidate.  (Block offsets are multiples of 8, so g % 8 == r.)  ~800 instructions instead of the
+  // ~2000 of a (candidate, r) mapping whose lanes walk every slot of every block.
   const FastDiv fdh(H);
-  const bool cand = a_of < p.n_yaw;
   const int jlo = max(bj, 0), jhi = min(bj + g.bbn, H);  // columns of the box inside the map
-  // blocks the box rows can touch: a contiguous range (pw_rowleaf = block of a row's first cell); the others sum to 0
-  const int row_lo = min(max(bi, 0), W - 1), row_hi = min(max(bi + g.bbn - 1, 0), W - 1);
-  const int lf_lo = p.pw_rowleaf[row_lo];
-  int lf_hi = p.pw_rowleaf[row_hi];
-  while (lf_hi + 1 < p.pw_nleaf && pwl[4 * (lf_hi + 1)] < (row_hi + 1) * H) ++lf_hi;  // the row's last cell may sit further on
+  const int row_lo = max(bi, 0), row_hi = min(bi + g.bbn - 1, W - 1);
+  int lf_lo = 0, lf_hi = -1;
+  if (jlo < jhi && row_lo <= row_hi) {  // blocks the box rows can touch: a contiguous range
+    lf_lo = p.pw_rowleaf[row_lo];
+    lf_hi = p.pw_rowleaf[row_hi];
+    while (lf_hi + 1 < p.pw_nleaf && pwl[4 * (lf_hi + 1)] < (row_hi + 1) * H) ++lf_hi;
+  }
   for (int k = lane; k < p.n_yaw * p.pw_nleaf; k += WAVE) {
     const int a = k / p.pw_nleaf, lf = k - a * p.pw_nleaf;
-    if (lf < lf_lo || lf > lf_hi) lsum[a * nnode + lf] = 0.0;
+    if (lf < lf_lo || lf > lf_hi) lsum[a * nnode + lf] = 0.0;  // the others sum to 0
   }
-  for (int lf = lf_lo; lf <= lf_hi; ++lf) {
-    const int off = pwl[4 * lf], m = pwl[4 * lf + 1], i_first = pwl[4 * lf + 2], i_last = pwl[4 * lf + 3];  // rows it covers
-    double res = 0.0;
-    if (i_last >= bi && i_first < bi + g.bbn && jlo < jhi) {
-      if (m < 8) {
-        double acc = 0.0;
-        if (r_of == 0 && cand)
-          for (int k = 0; k < m; ++k) {
-            int gi, gj;
-            fdh.divmod(off + k, gi, gj);
-            const int r = gi - bi, cc = gj - bj;
-            if (r >= 0 && r < g.bbn && cc >= 0 && cc < g.bbn && ((cm[r * g.bbn + cc] >> a_of) & 1)) acc += rew[r * g.bbn + cc];
-          }
-        res = acc;
-      } else {
-        // accumulator r_of of candidate a_of: elements off + r_of + 8 k in index order; only the box columns of the
-        // rows the block covers can be non-zero, so walk those (block offsets are multiples of 8: g % 8 == r_of)
-        const int m8 = m - (m & 7), gend = off + m8;
-        double acc = 0.0;
-        for (int i = max(i_first, bi); i <= min(i_last, bi + g.bbn - 1); ++i) {
-          const int glo = max(off, i * H + jlo), ghi = min(gend, i * H + jhi);
-          const int rowbase = (i - bi) * g.bbn - i * H - bj;  // box index = rowbase + g
-          for (int gq = glo + ((r_of - glo) & 7); gq < ghi; gq += 8) {
-            const int q = rowbase + gq;
-            if (cand && ((cm[q] >> a_of) & 1)) acc += rew[q];
-          }
-        }
-        // ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7))
-        double v = acc + shfl_f64(acc, lane + 1);
+  const int nchain = 8 * (lf_hi - lf_lo + 1);
+  const int per_row = (g.bbn + 7) >> 3;  // cells of one residue in a box row, at most
+  const int max_span = 127 / H + 2;      // grid rows a block of <= 128 cells can touch
+  for (int c0 = 0; c0 < nchain; c0 += WAVE) {
+    const int ch = c0 + lane;
+    const bool live = ch < nchain;
+    const int lf = lf_lo + min(ch, nchain - 1) / 8, r_of = lane & 7;
+    const int off = pwl[4 * lf], m = pwl[4 * lf + 1], i_first = pwl[4 * lf + 2], i_last = pwl[4 * lf + 3];
+    const int gend = off + (m - (m & 7));  // the last m % 8 elements of a block are added after its fold
+    double acc[7];
+#pragma unroll
+    for (int a = 0; a < 7; ++a) acc[a] = 0.0;
+    // uniform bounds, predicated body: every lane makes the same number of trips
+    const int i_lo = max(i_first, row_lo);
+    for (int di = 0; di < max_span; ++di) {
+      const int i = i_lo + di;
+      const bool row_on = live & (i <= min(i_last, row_hi));
+      const int glo = max(off, i * H + jlo), ghi = min(gend, i * H + jhi);
+      const int rowbase = (i - bi) * g.bbn - i * H - bj;  // box index = rowbase + g
+      const int g0 = glo + ((r_of - glo) & 7);
+      for (int k = 0; k < per_row; ++k) {
+        const int gq = g0 + 8 * k;
+        const bool on = row_on & (gq < ghi);
+        const int q = min(max(rowbase + gq, 0), g.ncell - 1);
+        const unsigned int bits = on ? (unsigned int)cm[q] : 0u;
+        const double rw = rew[q];
+#pragma unroll
+        for (int a = 0; a < 7; ++a) acc[a] = acc[a] + (((bits >> a) & 1u) ? rw : 0.0);  // + 0.0 changes nothing
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < 7; ++a) {
+      if (a < p.n_yaw) {  // ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7))
+        double v = acc[a] + shfl_f64(acc[a], lane + 1);
         v = v + shfl_f64(v, lane + 2);
         v = v + shfl_f64(v, lane + 4);
-        res = v;
-        if (r_of == 0 && cand)
-          for (int k = m8; k < m; ++k) {
+        if ((m & 7) != 0 && r_of == 0 && live)
+          for (int k = m - (m & 7); k < m; ++k) {  // numpy adds the block's last m % 8 elements one by one after the fold
             int gi, gj;
             fdh.divmod(off + k, gi, gj);
             const int r = gi - bi, cc = gj - bj;
             double x = 0.0;
-            if (r >= 0 && r < g.bbn && cc >= 0 && cc < g.bbn && ((cm[r * g.bbn + cc] >> a_of) & 1)) x = rew[r * g.bbn + cc];
-            res += x;
+            if (r >= 0 && r < g.bbn && cc >= 0 && cc < g.bbn && ((cm[r * g.bbn + cc] >> a) & 1)) x = rew[r * g.bbn + cc];
+            v += x;
           }
+        if (r_of == 0 && live) lsum[a * nnode + lf] = v;
       }
     }
-    if (r_of == 0 && cand) lsum[a_of * nnode + lf] = res;
   }
   wave_sync_lds();
+#if defined(D2D_GAZE_ABL) && D2D_GAZE_ABL == 5
+  if (lane == 0) act[e] = 0.0;
+  return;
+#endif
   // ---- the blocks' sums added in the recursion's order, level by level: the additions of one level are independent
   //      (lane = (candidate, addition)), every single one keeps numpy's left + right; argmax below (:116-125) ----
   {

@@ -1,0 +1,18 @@
+#!/bin/bash
+# Instruction counts of k_gaze cut off after each stage (builds libd2d_abl<n>.so with -DD2D_GAZE_ABL=<n>; results are
+# for counting only, the truncated kernels compute nothing useful).  Runs on the GPU box.
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+cd /tmp && export TMPDIR=/tmp
+for n in 1 2 3 4 5 full; do
+  lib=libd2d_abl$n.so; [ $n = full ] && lib=libd2d_hip.so
+  rm -rf $ROOT/gpurun_out/gabl/$n
+  D2D_LIB=$ROOT/gym-drone2d-activeperception_amd/csrc/$lib timeout -k 10 200 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES --output-format csv -d $ROOT/gpurun_out/gabl/$n -- python3 $ROOT/bench.py --no-persistent --steps 60 --warmup 40 --no-cpu-baseline --no-step-kernel --workers 0 --envs 1024 > $ROOT/gpurun_out/gabl_$n.log 2>&1
+  python3 - <<PY
+import csv,glob,collections
+f=glob.glob("$ROOT/gpurun_out/gabl/$n/**/*counter_collection.csv",recursive=True)[0]
+d=collections.defaultdict(list)
+for r in csv.DictReader(open(f)):
+    if "k_gaze" in r["Kernel_Name"]: d[r["Counter_Name"]].append(float(r["Counter_Value"]))
+print("cut $n:", {c: round(sum(v[-60:])/len(v[-60:])/1024,1) for c,v in d.items()})
+PY
+done
