@@ -935,9 +935,13 @@ __device__ __forceinline__ void gaze_env(const d2d_cfg &c, const d2d_state &s, c
     lf_hi = p.pw_rowleaf[row_hi];
     while (lf_hi + 1 < p.pw_nleaf && pwl[4 * (lf_hi + 1)] < (row_hi + 1) * H) ++lf_hi;
   }
-  for (int k = lane; k < p.n_yaw * p.pw_nleaf; k += WAVE) {
-    const int a = k / p.pw_nleaf, lf = k - a * p.pw_nleaf;
-    if (lf < lf_lo || lf > lf_hi) lsum[a * nnode + lf] = 0.0;  // the others sum to 0
+  {
+    const FastDiv fdl(p.pw_nleaf);  // no integer division: ~20 instructions each here
+    for (int k = lane; k < p.n_yaw * p.pw_nleaf; k += WAVE) {
+      int a, lf;
+      fdl.divmod(k, a, lf);
+      if (lf < lf_lo || lf > lf_hi) lsum[a * nnode + lf] = 0.0;  // the others sum to 0
+    }
   }
   const int nchain = 8 * (lf_hi - lf_lo + 1);
   const int per_row = (g.bbn + 7) >> 3;  // cells of one residue in a box row, at most
@@ -966,7 +970,8 @@ __device__ __forceinline__ void gaze_env(const d2d_cfg &c, const d2d_state &s, c
         const unsigned int bits = on ? (unsigned int)cm[q] : 0u;
         const double rw = rew[q];
 #pragma unroll
-        for (int a = 0; a < 7; ++a) acc[a] = acc[a] + (((bits >> a) & 1u) ? rw : 0.0);  // + 0.0 changes nothing
+        for (int a = 0; a < 7; ++a)
+          if (a < p.n_yaw) acc[a] = acc[a] + (((bits >> a) & 1u) ? rw : 0.0);  // + 0.0 changes nothing
       }
     }
 #pragma unroll
@@ -1000,8 +1005,11 @@ __device__ __forceinline__ void gaze_env(const d2d_cfg &c, const d2d_state &s, c
     const int *lstart = pwp + 2, *ops = pwp + 3 + nlev;
     for (int lv = 0; lv < nlev; ++lv) {
       const int o0 = lstart[lv], cnt = lstart[lv + 1] - o0;
+      const FastDiv fdc(cnt);
       for (int k = lane; k < p.n_yaw * cnt; k += WAVE) {
-        const int a = k / cnt, o = o0 + (k - a * cnt);
+        int a, ko;
+        fdc.divmod(k, a, ko);
+        const int o = o0 + ko;
         const int dst = ops[3 * o], lft = ops[3 * o + 1], rgt = ops[3 * o + 2];
         lsum[a * nnode + dst] = lsum[a * nnode + lft] + lsum[a * nnode + rgt];
       }
