@@ -1340,17 +1340,6 @@ __device__ __forceinline__ const ClosedArgs *uniform_ptr(const ClosedArgs *p) {
 }
 
 template <int SPEC>
-__device__ __attribute__((noinline)) void ph_gaze(const ClosedArgs *ap, int e_, int lds_off_) {
-  const ClosedArgs *__restrict__ a = uniform_ptr(ap);
-  const int e = __builtin_amdgcn_readfirstlane(e_), lane = threadIdx.x & (WAVE - 1);
-  char *base = d2d_lds + __builtin_amdgcn_readfirstlane(lds_off_);
-  d2d_cfg c = a->c;
-  if (SPEC != 0) spec_default_apply(c);
-  gaze_env(c, a->s, a->p, a->init, a->on_done == D2D_DONE_RESET, e, lane, base);
-  wave_sync_global();
-}
-
-template <int SPEC>
 __device__ __attribute__((noinline)) void ph_plan(const ClosedArgs *ap, int e_, int lds_off_) {
   const ClosedArgs *__restrict__ a = uniform_ptr(ap);
   const int e = __builtin_amdgcn_readfirstlane(e_), lane = threadIdx.x & (WAVE - 1);
@@ -1358,6 +1347,26 @@ __device__ __attribute__((noinline)) void ph_plan(const ClosedArgs *ap, int e_, 
   d2d_cfg c = a->c;
   if (SPEC != 0) spec_default_apply(c);
   plan_env(c, a->s, a->p, e, lane, base);
+  wave_sync_global();
+}
+
+// gaze + the stages that follow it in one call (one set of callee-saved registers, one fence fewer per step)
+template <int SPEC, uint32_t STAGES>
+__device__ __attribute__((noinline)) void ph_gaze_stages(const ClosedArgs *ap, int e_, int lds_off_) {
+  const ClosedArgs *__restrict__ a = uniform_ptr(ap);
+  const int e = __builtin_amdgcn_readfirstlane(e_), lane = threadIdx.x & (WAVE - 1);
+  char *base = d2d_lds + __builtin_amdgcn_readfirstlane(lds_off_);
+  d2d_cfg c = a->c;
+  if (SPEC != 0) spec_default_apply(c);
+  gaze_env(c, a->s, a->p, a->init, a->on_done == D2D_DONE_RESET, e, lane, base);
+  wave_sync_global();
+  const int wpb = (SPEC == 1 || SPEC == 2) ? WAVES_PER_BLOCK : (int)(blockDim.x / WAVE);
+  const Geom g = make_geom(c, wpb, spec_ncap(SPEC));
+  const LdsView L = carve(base, g, c.L);
+  EnvRegs r;
+  load_regs(a->s, e, r);
+  run_env(c, a->s, e, lane, STAGES, g, L, a->s.action[e], r);
+  if (lane == 0) store_regs(a->s, e, r);
   wave_sync_global();
 }
 
@@ -1393,13 +1402,12 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK, D2D_MIN_WAVES) void k_closed
 #pragma unroll 1
   for (int t = 0; t < nsteps; ++t) {
     if (freeze && a->s.flags[(size_t)e * 4 + D2D_F_DONE] != 0) break;  // one episode per env: it stays as it ended
-    ph_gaze<SPEC>(a, e, off);
     if (split) {
-      ph_stages<SPEC, D2D_ST_PERCEIVE>(a, e, off);
+      ph_gaze_stages<SPEC, D2D_ST_PERCEIVE>(a, e, off);
       ph_plan<SPEC>(a, e, off);
       ph_stages<SPEC, D2D_ST_ACT>(a, e, off);
     } else {
-      ph_stages<SPEC, D2D_ST_ALL>(a, e, off);
+      ph_gaze_stages<SPEC, D2D_ST_ALL>(a, e, off);
     }
   }
 }
