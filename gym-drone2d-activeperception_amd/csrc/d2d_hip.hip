@@ -1339,14 +1339,28 @@ __device__ __forceinline__ const ClosedArgs *uniform_ptr(const ClosedArgs *p) {
   return (const ClosedArgs *)(((unsigned long long)hi << 32) | lo);
 }
 
+// The planner stage as two calls: the part every step runs (small: few registers to save), and the search, called
+// only when the trajectory is empty (a few percent of the steps).
 template <int SPEC>
-__device__ __attribute__((noinline)) void ph_plan(const ClosedArgs *ap, int e_, int lds_off_) {
+__device__ __attribute__((noinline)) int ph_plan_quick(const ClosedArgs *ap, int e_, int lds_off_) {
   const ClosedArgs *__restrict__ a = uniform_ptr(ap);
   const int e = __builtin_amdgcn_readfirstlane(e_), lane = threadIdx.x & (WAVE - 1);
   char *base = d2d_lds + __builtin_amdgcn_readfirstlane(lds_off_);
   d2d_cfg c = a->c;
   if (SPEC != 0) spec_default_apply(c);
-  plan_env(c, a->s, a->p, e, lane, base);
+  const bool need = plan_env_quick(c, a->s, a->p, e, lane, base);
+  wave_sync_global();
+  return need ? 1 : 0;
+}
+
+template <int SPEC>
+__device__ __attribute__((noinline)) void ph_plan_search(const ClosedArgs *ap, int e_, int lds_off_) {
+  const ClosedArgs *__restrict__ a = uniform_ptr(ap);
+  const int e = __builtin_amdgcn_readfirstlane(e_), lane = threadIdx.x & (WAVE - 1);
+  char *base = d2d_lds + __builtin_amdgcn_readfirstlane(lds_off_);
+  d2d_cfg c = a->c;
+  if (SPEC != 0) spec_default_apply(c);
+  plan_env_search(c, a->s, a->p, e, lane, base);
   wave_sync_global();
 }
 
@@ -1404,7 +1418,7 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK, D2D_MIN_WAVES) void k_closed
     if (freeze && a->s.flags[(size_t)e * 4 + D2D_F_DONE] != 0) break;  // one episode per env: it stays as it ended
     if (split) {
       ph_gaze_stages<SPEC, D2D_ST_PERCEIVE>(a, e, off);
-      ph_plan<SPEC>(a, e, off);
+      if (__builtin_amdgcn_readfirstlane(ph_plan_quick<SPEC>(a, e, off))) ph_plan_search<SPEC>(a, e, off);
       ph_stages<SPEC, D2D_ST_ACT>(a, e, off);
     } else {
       ph_gaze_stages<SPEC, D2D_ST_ALL>(a, e, off);

@@ -153,6 +153,7 @@ struct SearchLds {
   double *rv;       // [64] reduction / de-duplication values (candidate costs)
   long long *rk;    // [64] de-duplication keys
   int *ri;          // [64] reduction indices
+  int *misc;        // [4] misc[0] = number of active trackers staged by the quick part of the stage
   double *tot;      // [D2D_SEARCH_LDS_NODES] total_cost of the first nodes, +inf once closed (the min() scan reads these)
   unsigned char *map;  // [W * H] copy of the explored map for the collision probes, or null when it does not fit
 };
@@ -517,28 +518,60 @@ __host__ __device__ inline int plan_wave_bytes(int N, int nu, int n_sample, int 
   const int ncap = ((N > 0 ? N : 1) + 3) & ~3;
   const int nu4 = (nu + 3) & ~3, ns4 = (2 * n_sample + 3) & ~3;
   const int mapb = WH <= D2D_SEARCH_LDS_MAP ? ((WH + 15) & ~15) : 0;
-  return 6 * 8 * ncap + 8 * (nu4 + ns4) + 8 * 64 + 8 * 64 + 4 * 64 + 128 * 4 + 8 * D2D_SEARCH_LDS_NODES + mapb;
+  return 6 * 8 * ncap + 8 * (nu4 + ns4) + 8 * 64 + 8 * 64 + 4 * 64 + 128 * 4 + 16 + 8 * D2D_SEARCH_LDS_NODES + mapb;
 }
 
 // replan_check + plan + head waypoint of env e by one wave; `base`: plan_wave_bytes() bytes of LDS
-__device__ __forceinline__ void plan_env(const d2d_cfg &c, const d2d_state &s, const d2d_plan &p, int e, int lane, char *base) {
+__device__ __forceinline__ void plan_carve(const d2d_cfg &c, const d2d_plan &p, char *base, TrkView &T, SearchLds &S) {
   const int N = c.N, ncap = ((N > 0 ? N : 1) + 3) & ~3;
-  TrkView T;
   T.mx = (double *)base;
   T.my = T.mx + ncap;
   T.vx = T.my + ncap;
   T.vy = T.vx + ncap;
   T.lim_plan = T.vy + ncap;
   T.lim_replan = T.lim_plan + ncap;
-  SearchLds S;
   S.us = T.lim_replan + ncap;
   S.st = S.us + ((p.nu + 3) & ~3);
   S.rv = S.st + ((2 * p.n_sample + 3) & ~3);
   S.rk = (long long *)(S.rv + 64);
   S.ri = (int *)(S.rk + 64);
   S.chain = S.ri + 64;
-  S.tot = (double *)(S.chain + 128);
+  S.misc = S.chain + 128;
+  S.tot = (double *)(S.misc + 4);
   S.map = (c.W * c.H <= D2D_SEARCH_LDS_MAP) ? (unsigned char *)(S.tot + D2D_SEARCH_LDS_NODES) : nullptr;
+}
+
+// Writes the head step_pos will consume (utils.py:733-739) and the planner's result; pops the head.
+__device__ __forceinline__ void plan_emit(const d2d_state &s, const d2d_plan &p, int e, int lane, int head, int stored, int ok) {
+  if (lane == 0) {
+    const double *traj = p.traj + (size_t)e * p.traj_cap * 4;
+    int *hdr = p.traj_hdr + (size_t)e * 2;
+    unsigned char *plan_ok = (unsigned char *)s.plan_ok, *wp_valid = (unsigned char *)s.wp_valid;
+    double *wp = (double *)s.wp + (size_t)e * 6;
+    plan_ok[e] = (unsigned char)ok;
+    if (stored - head > 0) {
+      const double *w = traj + (size_t)head * 4;
+      wp[0] = w[0]; wp[1] = w[1]; wp[2] = w[2]; wp[3] = w[3]; wp[4] = 0.0; wp[5] = 0.0;
+      wp_valid[e] = 1;
+      head += 1;
+    } else {
+      wp_valid[e] = 0;
+      for (int i = 0; i < 6; ++i) wp[i] = 0.0;
+    }
+    hdr[0] = head;
+    hdr[1] = stored;
+  }
+}
+
+// The part of the planner stage every step runs: tracker bookkeeping (the active ones staged in LDS, where a search
+// that follows finds them), replan_check, and -- when the trajectory is still there -- its head.  Returns true when
+// the trajectory is empty, i.e. Primitive.plan has to search (plan_env_search).  Kept apart from the search so that,
+// as a called function in the persistent loop, the common path does not pay the search's register saves.
+__device__ __forceinline__ bool plan_env_quick(const d2d_cfg &c, const d2d_state &s, const d2d_plan &p, int e, int lane, char *base) {
+  const int N = c.N;
+  TrkView T;
+  SearchLds S;
+  plan_carve(c, p, base, T, S);
   const double inv_scale = 1.0 / c.scale;
   const unsigned char *__restrict__ dm = s.dmap + (size_t)e * c.W * c.H;
   // ---- trackers: archive bookkeeping (utils.py:184,238) and the active ones into LDS ----
@@ -599,36 +632,40 @@ __device__ __forceinline__ void plan_env(const d2d_cfg &c, const d2d_state &s, c
     }
     if (__any(bad)) head = stored = 0;
   }
-  // ---- plan, traj_planner.py:125-218 ----
-  int ok = 1;
-  if (stored - head == 0) {
-    head = 0;
-    // A search is a long chain of short dependent steps and, in the persistent loop, what the slowest env of a launch
-    // spends its time on; its wave shares the SIMD with three others that mostly run throughput phases.  Raised issue
-    // priority lets it go first whenever it is ready (0.78 ms -> its stand-alone 0.46 ms is the range at stake).
-    __builtin_amdgcn_s_setprio(3);
-    stored = plan_search(c, s, p, e, lane, T, S, dm, inv_scale);
-    __builtin_amdgcn_s_setprio(0);
-    ok = stored > 0 ? 1 : 0;
-    wave_sync_global();
-  }
-  // ---- the head step_pos will consume (utils.py:733-739) ----
-  if (lane == 0) {
-    unsigned char *plan_ok = (unsigned char *)s.plan_ok, *wp_valid = (unsigned char *)s.wp_valid;
-    double *wp = (double *)s.wp + (size_t)e * 6;
-    plan_ok[e] = (unsigned char)ok;
-    if (stored - head > 0) {
-      const double *w = traj + (size_t)head * 4;
-      wp[0] = w[0]; wp[1] = w[1]; wp[2] = w[2]; wp[3] = w[3]; wp[4] = 0.0; wp[5] = 0.0;
-      wp_valid[e] = 1;
-      head += 1;
-    } else {
-      wp_valid[e] = 0;
-      for (int i = 0; i < 6; ++i) wp[i] = 0.0;
+  if (stored - head == 0) {  // Primitive.plan has to search: the trackers (and their count) wait in LDS
+    if (lane == 0) {
+      hdr[0] = 0;
+      hdr[1] = 0;
+      S.misc[0] = nact;
     }
-    hdr[0] = head;
-    hdr[1] = stored;
+    wave_sync_lds();
+    return true;
   }
+  plan_emit(s, p, e, lane, head, stored, 1);  // traj_planner.py:128-129: a non-empty trajectory is kept
+  return false;
+}
+
+// Primitive.plan's search (traj_planner.py:125-218) for an env whose plan_env_quick returned true.
+__device__ __forceinline__ void plan_env_search(const d2d_cfg &c, const d2d_state &s, const d2d_plan &p, int e, int lane, char *base) {
+  TrkView T;
+  SearchLds S;
+  plan_carve(c, p, base, T, S);
+  T.n = S.misc[0];  // the trackers are still in LDS
+  const double inv_scale = 1.0 / c.scale;
+  const unsigned char *__restrict__ dm = s.dmap + (size_t)e * c.W * c.H;
+  // A search is a long chain of short dependent steps and, in the persistent loop, what the slowest env of a launch
+  // spends its time on; its wave shares the SIMD with three others that mostly run throughput phases.  Raised issue
+  // priority lets it go first whenever it is ready (0.78 ms -> its stand-alone 0.46 ms is the range at stake).
+  __builtin_amdgcn_s_setprio(3);
+  const int stored = plan_search(c, s, p, e, lane, T, S, dm, inv_scale);
+  __builtin_amdgcn_s_setprio(0);
+  wave_sync_global();
+  plan_emit(s, p, e, lane, 0, stored, stored > 0 ? 1 : 0);
+}
+
+// replan_check + plan + head waypoint of env e by one wave; `base`: plan_wave_bytes() bytes of LDS
+__device__ __forceinline__ void plan_env(const d2d_cfg &c, const d2d_state &s, const d2d_plan &p, int e, int lane, char *base) {
+  if (plan_env_quick(c, s, p, e, lane, base)) plan_env_search(c, s, p, e, lane, base);
 }
 
 __global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK) void k_plan(d2d_cfg c, d2d_state s, d2d_plan p, int skip_done) {
