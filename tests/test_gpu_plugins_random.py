@@ -1,6 +1,8 @@
 """Randomised closed-loop parity (run with -m gpu): seeded random configurations -- agent count / radius / speed, drone
 speed (other primitive sets), pillars, static maps, view cone -- device plugins vs the oracle, every field of the env
 and plugin state bit for bit, with auto reset and with freeze."""
+import os
+
 import numpy as np
 import pytest
 
@@ -25,7 +27,10 @@ def _random_cfg(rng):
     return kw
 
 
-@pytest.mark.parametrize('seed', range(48))
+N_SEEDS = int(os.environ.get('D2D_RANDOM_SEEDS', '48'))      # a soak run sets this higher
+
+
+@pytest.mark.parametrize('seed', range(N_SEEDS))
 def test_random_closed_loop_matches_oracle(pkg, hip, oracle, seed):
     rng = np.random.RandomState(1000 + seed)
     kw = _random_cfg(rng)
