@@ -39,6 +39,56 @@ __device__ __forceinline__ double shfl_f64(double v, int src) {
   return __hiloint2double(hi, lo);
 }
 
+// Value of lane + N (N = 1, 2, 4) inside the lane's row of 16: a DPP row shift, no LDS round trip.  Only used where
+// the source lane lies in the same row (groups of 8 neighbouring lanes).
+template <int N>
+__device__ __forceinline__ double row_shl_f64(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, 0x100 + N, 0xf, 0xf, false);  // row_shl:N
+  hi = __builtin_amdgcn_update_dpp(hi, hi, 0x100 + N, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+
+// Value of lane - N inside the lane's row of 16 (DPP row_shr:N); lanes without a source keep their own value.
+template <int N>
+__device__ __forceinline__ int row_shr_i32(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x110 + N, 0xf, 0xf, false); }
+template <int N>
+__device__ __forceinline__ double row_shr_f64(double v) {
+  return __hiloint2double(row_shr_i32<N>(__double2hiint(v)), row_shr_i32<N>(__double2loint(v)));
+}
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+
+// Lexicographic (cost, slot) minimum over the wave, returned wave-uniform: four DPP steps fold every row of 16 lanes
+// into its last lane, four readlanes fold the rows.  (+inf, INT_MAX) is "no candidate".
+__device__ __forceinline__ int wave_argmin(double t, int idx) {
+#define D2D_ARGMIN_STEP(N)                                             \
+  {                                                                    \
+    const double t2 = row_shr_f64<N>(t);                               \
+    const int i2 = row_shr_i32<N>(idx);                                \
+    const bool take = (t2 < t) | ((t2 == t) & (i2 < idx));             \
+    t = take ? t2 : t;                                                 \
+    idx = take ? i2 : idx;                                             \
+  }
+  D2D_ARGMIN_STEP(1)
+  D2D_ARGMIN_STEP(2)
+  D2D_ARGMIN_STEP(4)
+  D2D_ARGMIN_STEP(8)
+#undef D2D_ARGMIN_STEP
+  double b = readlane_f64(t, 15);
+  int bi = __builtin_amdgcn_readlane(idx, 15);
+#pragma unroll
+  for (int row = 1; row < 4; ++row) {
+    const double t2 = readlane_f64(t, 16 * row + 15);
+    const int i2 = __builtin_amdgcn_readlane(idx, 16 * row + 15);
+    const bool take = (t2 < b) | ((t2 == b) & (i2 < bi));
+    b = take ? t2 : b;
+    bi = take ? i2 : bi;
+  }
+  return bi;
+}
+
 struct TrkView {  // active trackers of the env, compacted into LDS
   double *mx, *my, *vx, *vy;
   double *lim_plan, *lim_replan;  // norm(d) <= L rewritten as d.d <= T(L), see sq_threshold
@@ -212,6 +262,7 @@ __device__ int plan_search(const d2d_cfg &c, const d2d_state &s, const d2d_plan 
   bool overflow = false;
   const int nprim = p.nu * p.nu;
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  const FastDiv fd_nu(p.nu), fd_ns(p.n_sample);
   for (;;) {
     itr += 1;
     if (open_n == 0 || itr >= p.max_itr) break;
@@ -249,49 +300,7 @@ __device__ int plan_search(const d2d_cfg &c, const d2d_state &s, const d2d_plan 
         bidx = take ? si : bidx;
       }
     }
-    // lexicographic (cost, slot) minimum over the wave through LDS: 64 -> 8 -> 1, every lane ends with the winner
-    S.rv[lane] = best;
-    S.ri[lane] = bidx;
-    wave_sync_lds();
-    {
-      double v8[8];
-      int i8[8];
-      const int g0 = (lane & 7) * 8;
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        v8[k] = S.rv[g0 + k];
-        i8[k] = S.ri[g0 + k];
-      }
-      double b = v8[0];
-      int bi = i8[0];
-#pragma unroll
-      for (int k = 1; k < 8; ++k) {
-        const bool take = (v8[k] < b) | ((v8[k] == b) & (i8[k] < bi));
-        b = take ? v8[k] : b;
-        bi = take ? i8[k] : bi;
-      }
-      wave_sync_lds();
-      if (lane < 8) {
-        S.rv[lane] = b;
-        S.ri[lane] = bi;
-      }
-      wave_sync_lds();
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        v8[k] = S.rv[k];
-        i8[k] = S.ri[k];
-      }
-      b = v8[0];
-      bi = i8[0];
-#pragma unroll
-      for (int k = 1; k < 8; ++k) {
-        const bool take = (v8[k] < b) | ((v8[k] == b) & (i8[k] < bi));
-        b = take ? v8[k] : b;
-        bi = take ? i8[k] : bi;
-      }
-      bidx = bi;
-      wave_sync_lds();
-    }
+    bidx = wave_argmin(best, bidx);  // first minimal entry in slot order
     if (__builtin_amdgcn_readfirstlane(bidx) == 0x7fffffff) {
       // every open node has a non-finite cost (wild inputs): the literal scan over the state plane decides
       int fb = 0x7fffffff;
@@ -323,7 +332,8 @@ __device__ int plan_search(const d2d_cfg &c, const d2d_state &s, const d2d_plan 
     for (int p0 = 0; p0 < nprim && !overflow; p0 += WAVE) {
       const int pi = p0 + lane;
       bool ok = pi < nprim;
-      const int ia = ok ? pi / p.nu : 0, ja = ok ? pi - ia * p.nu : 0;
+      int ia, ja;
+      fd_nu.divmod(ok ? pi : 0, ia, ja);  // no integer divisions in the loop: ~25 instructions each
       const double ax = S.us[ia], ay = S.us[ja];
       const double hx = ax / 2, hy = ay / 2;
       const double vex = vx + (2 * H) * hx, vey = vy + (2 * H) * hy;  // :172,183
@@ -345,9 +355,9 @@ __device__ int plan_search(const d2d_cfg &c, const d2d_state &s, const d2d_plan 
         for (int q0 = 0; q0 < npair; q0 += WAVE) {
           const int q = q0 + lane;
           if (q < npair) {
-            const int pr = q / p.n_sample, si = q - pr * p.n_sample;
-            const int spi = plist[pr];
-            const int sia = spi / p.nu, sja = spi - sia * p.nu;
+            int pr, si, sia, sja;
+            fd_ns.divmod(q, pr, si);
+            fd_nu.divmod(plist[pr], sia, sja);
             const double shx = S.us[sia] / 2, shy = S.us[sja] / 2;
             const double t = S.st[2 * si], t2 = S.st[2 * si + 1];
             const double sx = rint(__builtin_fma(t2, shx, px + t * vx)), sy = rint(__builtin_fma(t2, shy, py + t * vy));
@@ -994,7 +1004,11 @@ __device__ __forceinline__ void gaze_env(const d2d_cfg &c, const d2d_state &s, c
     for (int a = 0; a < 7; ++a) acc[a] = 0.0;
     // uniform bounds, predicated body: every lane makes the same number of trips
     const int i_lo = max(i_first, row_lo);
-    for (int di = 0; di < max_span; ++di) {
+    // rows to walk: the largest span among the blocks of this pass (wave-uniform), usually 3 of the possible 4
+    const int my_span = live ? min(i_last, row_hi) - i_lo + 1 : 0;
+    int span = 1;
+    for (int k = 2; k <= max_span; ++k) span = __any(my_span >= k) ? k : span;
+    for (int di = 0; di < span; ++di) {
       const int i = i_lo + di;
       const bool row_on = live & (i <= min(i_last, row_hi));
       const int glo = max(off, i * H + jlo), ghi = min(gend, i * H + jhi);
@@ -1014,9 +1028,9 @@ __device__ __forceinline__ void gaze_env(const d2d_cfg &c, const d2d_state &s, c
 #pragma unroll
     for (int a = 0; a < 7; ++a) {
       if (a < p.n_yaw) {  // ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7))
-        double v = acc[a] + shfl_f64(acc[a], lane + 1);
-        v = v + shfl_f64(v, lane + 2);
-        v = v + shfl_f64(v, lane + 4);
+        double v = acc[a] + row_shl_f64<1>(acc[a]);
+        v = v + row_shl_f64<2>(v);
+        v = v + row_shl_f64<4>(v);
         if ((m & 7) != 0 && r_of == 0 && live)
           for (int k = m - (m & 7); k < m; ++k) {  // numpy adds the block's last m % 8 elements one by one after the fold
             int gi, gj;
