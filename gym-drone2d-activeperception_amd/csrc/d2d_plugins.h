@@ -224,6 +224,9 @@ __device__ int plan_search(const d2d_cfg &c, const d2d_state &s, const d2d_plan 
   const double tx = s.target[(size_t)e * 2], ty = s.target[(size_t)e * 2 + 1];
   const double *dr = s.drone + (size_t)e * D2D_DF;
 
+  unsigned long long spa = 0, spb = 0;
+  (void)spa; (void)spb;
+  SP_T(spa);
   for (int i = lane; i < p.hash_cap; i += WAVE) tab[i] = 0;
   for (int i = lane; i < p.nu; i += WAVE) S.us[i] = p.u_space[i];
   for (int i = lane; i < 2 * p.n_sample; i += WAVE) S.st[i] = p.sample_t[i];
@@ -258,6 +261,8 @@ __device__ int plan_search(const d2d_cfg &c, const d2d_state &s, const d2d_plan 
     S.tot[0] = nd.total[0];
   }
   wave_sync_global();
+  SP_T(spb);
+  SP_ADD(10, spa, spb);
   int nn = 1, open_n = 1, goal = -1, itr = 0, expansions = 0;
   bool overflow = false;
   const int nprim = p.nu * p.nu;
@@ -489,6 +494,7 @@ __device__ int plan_search(const d2d_cfg &c, const d2d_state &s, const d2d_plan 
     if (overflow) stat[3] = 1;
   }
   if (goal < 0 || overflow) return 0;
+  SP_T(spa);
   // ---- :207-216: waypoints of every primitive on the path, start side first ----
   int depth = 0;
   for (int q = goal; q != 0 && depth <= 128; q = nd.link[q].x) depth += 1;  // bounded: a wave must always terminate
@@ -520,6 +526,11 @@ __device__ int plan_search(const d2d_cfg &c, const d2d_state &s, const d2d_plan 
       o[3] = pvy + tt * hy;
     }
   }
+  SP_T(spb);
+  SP_ADD(11, spa, spb);
+#ifdef D2D_SEARCH_PROF
+  if (e == 0 && lane == 0) d2d_search_prof[12] += 1;
+#endif
   return total;
 }
 
