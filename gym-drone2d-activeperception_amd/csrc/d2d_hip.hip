@@ -213,9 +213,12 @@ __device__ __forceinline__ int cell_fast(double v, double s, double inv_s) {
 struct CellDiv {
   float inv;
   int s;
-  __device__ __forceinline__ explicit CellDiv(double scale) : inv(1.0f / (float)scale), s((int)scale) {}
+  bool by10;  // scale 10 on a map below 81920 px: floor(n / 10) == (n * 52429) >> 19 exactly, in 32-bit arithmetic
+  __device__ __forceinline__ CellDiv(double scale, double max_px)
+      : inv(1.0f / (float)scale), s((int)scale), by10(scale == 10.0 && max_px <= 81919.0) {}
   __device__ __forceinline__ int operator()(double v) const {
     const int vi = __double2int_rz(v);  // truncation == floor for v >= 0; saturates / 0 for wild or NaN inputs
+    if (by10) return (int)(((unsigned int)vi * 52429u) >> 19);  // a live sample lies inside the map; others are clamped by the caller
     int q = (int)((float)vi * inv);
     const int r = vi - q * s;
     q += (r >= s) ? 1 : 0;
@@ -593,7 +596,7 @@ __device__ __forceinline__ void ray_march(const d2d_cfg &c, const Geom &g, const
                                           int ncand, double x0, double y0, const Tile &wt, const Tile &ct, bool patch,
                                           unsigned char *__restrict__ dm) {
   const int H = c.H;
-  const CellDiv cell(c.scale);
+  const CellDiv cell(c.scale, fmax(c.W_px, c.H_px));
   const double depth2 = c.depth * c.depth;
   const bool mask_path = ncand <= 32;
   const unsigned char *gtw = (const unsigned char *)L.gtw;
