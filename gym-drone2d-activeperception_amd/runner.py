@@ -69,13 +69,15 @@ class ExperimentBatch:
     def __init__(self, params, num_envs, device='cuda:0', backend=None, workers=0):
         from .vec_env import VecDrone2DEnv, build_worlds
         p = with_defaults(params)
-        if p.gaze_method not in ('Oxford',) or p.planner not in ('Primitive', 'NoMove'):
-            raise NotImplementedError('ExperimentBatch runs the device plugins: gaze_method Oxford, planner Primitive / NoMove '
-                                      '(use Experiment / HostPluginBatch for the host plugins)')
+        if p.gaze_method not in ('Oxford', 'Rotating', 'NoControl') or p.planner not in ('Primitive', 'NoMove'):
+            raise NotImplementedError('ExperimentBatch runs the device plugins: gaze_method Oxford / Rotating / NoControl, planner '
+                                      'Primitive / NoMove (use Experiment / HostPluginBatch for the host plugins)')
+        if p.gaze_method == 'NoControl':
+            p.drone_view_range = 360                                   # experiment.py:28-29
         self.params = p
         worlds = build_worlds(p, num_envs, workers=workers)
         self.env = VecDrone2DEnv(p, num_envs, device=device, backend=backend, planner=p.planner, worlds=worlds,
-                                 device_plugins=True, gaze='Oxford')
+                                 device_plugins=True, gaze=p.gaze_method)
         self.max_steps = int(np.ceil(p.max_flight_time / p.dt)) + 1           # freezing ends every episode by then
 
     def run(self, chunk=None):

@@ -74,11 +74,18 @@ class VecDrone2DEnv:
         if device_plugins:
             from .device_plugins import PluginState
             gaze = gaze if gaze is not None else self.params.gaze_method
-            if planner not in ('Primitive', 'NoMove') or gaze not in ('Oxford', 'external', None):
-                raise NotImplementedError(f'device plugins: planner {planner!r} / gaze {gaze!r} (device: Primitive, NoMove / Oxford)')
+            if planner not in ('Primitive', 'NoMove') or gaze not in ('Oxford', 'Rotating', 'NoControl', 'external', None):
+                raise NotImplementedError(f'device plugins: planner {planner!r} / gaze {gaze!r} '
+                                          '(device: Primitive, NoMove / Oxford, Rotating, NoControl)')
             self.plugins = PluginState(self.params, self.cfg, self.device, self.tracker_radius.numpy(),
                                        planner=planner, gaze=gaze or 'external')
             self._plan = self.plugins.struct()
+            # the constant policies of the reference need no kernel: Rotating.plan -> 1 (yaw_planner.py:136-142),
+            # NoControl.plan -> 0 (:10-16); the action stays resident
+            if gaze == 'Rotating':
+                self.state.action.fill_(1.0)
+            elif gaze == 'NoControl':
+                self.state.action.fill_(0.0)
 
     # ------------------------------------------------------------------ gym-like surface (batched)
     @property

@@ -159,3 +159,19 @@ def test_oracle_closed_loop_entry_point_and_auto_reset(pkg, oracle):
         assert torch.equal(env.state.t[name], env2.state.t[name]), name
     for name in ('traj_hdr', 'seen_step', 'trk_radius', 'trk_prev'):
         assert torch.equal(env.plugins.t[name], env2.plugins.t[name]), name
+
+
+def test_constant_gaze_policies_on_the_plugin_path(pkg, oracle):
+    """gaze='NoControl' / 'Rotating' with device_plugins: the reference's constant policies (yaw_planner.py:10-16,
+    136-142) are a resident action of 0 / 1 -- NoControl + NoMove over 30 closed-loop steps is 30 plain steps at action 0
+    (the survivability rollout, cal_difficulty_survivability.py:53-60), Rotating the same at action 1."""
+    from drone2d_amd import vec_env
+    for gaze, a in (('NoControl', 0.0), ('Rotating', 1.0)):
+        p = pkg.Params(planner='NoMove', gaze_method=gaze, agent_number=10, agent_radius=15, agent_max_speed=20, map_id=1)
+        env = vec_env.VecDrone2DEnv(p, 3, backend=oracle, planner='NoMove', device_plugins=True, gaze=gaze)
+        ref = vec_env.VecDrone2DEnv(p, 3, backend=oracle, planner='NoMove')
+        env.closed_loop(30)
+        for _ in range(30):
+            ref.step(torch.full((3,), a, dtype=torch.float64))
+        for name in ('agents', 'gt', 'dmap', 'drone', 'counters', 'kf', 'active', 'flags'):
+            assert torch.equal(env.state.t[name], ref.state.t[name]), (gaze, name)

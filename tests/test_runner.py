@@ -67,6 +67,29 @@ def _batch_rows(pkg, backend, device, B=4):
     assert np.array_equal(before.cpu().numpy(), eb.env.state.drone.cpu().numpy())
 
 
+def _batch_row_rotating(pkg, backend, device):
+    """The reference's Rotating + Primitive row (experiment_rows r2) with the planner on the device and the constant
+    gaze policy as a resident action."""
+    from drone2d_amd import runner
+    fx = load('experiment_rows')
+    kw = json.loads(str(fx['r2_cfg']))
+    assert kw['gaze_method'] == 'Rotating' and kw['planner'] == 'Primitive'
+    p = pkg.Params(debug=True, **kw)
+    p.render = False
+    rows = runner.ExperimentBatch(p, 2, device=device, backend=backend).run()
+    got = np.array([float(v) for v in rows[0][12:]], dtype=np.float64)
+    assert np.allclose(got, fx['r2_row'], rtol=0, atol=1e-9, equal_nan=True), (got, fx['r2_row'])
+
+
+def test_experiment_batch_rotating_cpu(pkg, oracle):
+    _batch_row_rotating(pkg, oracle, 'cpu')
+
+
+@pytest.mark.gpu
+def test_experiment_batch_rotating_gpu(pkg, hip):
+    _batch_row_rotating(pkg, hip, hip.device)
+
+
 def test_experiment_batch_rows_cpu(pkg, oracle):
     _batch_rows(pkg, oracle, 'cpu', B=3)
 
