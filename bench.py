@@ -31,6 +31,8 @@ sys.path.insert(0, ROOT)
 
 ALGO_BYTES_PER_ENV_STEP = 3844      # N=10, c=9, R=50, S=10, L=33
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E 8 TB/s
+N_SIMD = 256 * 4                    # 256 CUs x 4 SIMDs
+CLOCK_HZ = 2.4e9                    # nominal shader clock (the chip runs at or below it under load)
 
 
 def synth_plan(torch, T, B, W_px, H_px, seed, device):
@@ -133,7 +135,22 @@ def step_kernel_leg(torch, env, params, rank, device, B, K=500, Wm=200):
             'launches': K, 'repetitions_us': reps, 'envs_per_launch': B, 'launch_us': launch_us, 'env_steps_per_s': B / (launch_us * 1e-6),
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': _pmc('step_kernel_hbm_bytes_per_launch'),
-                         'algo_bytes_per_env_step': ALGO_BYTES_PER_ENV_STEP}}
+                         'algo_bytes_per_env_step': ALGO_BYTES_PER_ENV_STEP},
+            'valu': _valu('k_stages', B / (launch_us * 1e-6))}
+
+
+def _valu(kernel, env_steps_per_s_per_gpu):
+    """VALU-issue view of a kernel ("report both the HBM fraction and VALU utilisation"): the vector-pipe cycles
+    one env-step holds a SIMD (rocprofv3 --pmc SQ_ACTIVE_INST_VALU, committed in profiles/pmc_latest.json) against
+    1024 SIMDs x 2.4 GHz, with the rate measured live in this run."""
+    k = _pmc(kernel) or {}
+    busy = k.get('valu_busy_cycles_per_env_step')
+    if not busy:
+        return None
+    ceiling = N_SIMD * CLOCK_HZ / busy
+    return {'insts_per_env_step': k.get('valu_insts_per_env_step'), 'salu_insts_per_env_step': k.get('salu_insts_per_env_step'),
+            'busy_cycles_per_env_step': busy, 'ceiling_env_steps_per_s': ceiling, 'frac': env_steps_per_s_per_gpu / ceiling,
+            'note': 'issue ceiling of this instruction stream = 1024 SIMDs x 2.4 GHz / vector-pipe cycles per env-step (PMC)'}
 
 
 def _pmc(key):
@@ -258,6 +275,7 @@ def main():
                          'algo_bytes_per_env_step': ALGO_BYTES_PER_ENV_STEP,
                          'note': 'algorithmic bytes of the Drone2DEnv2.step stages (SURVEY 8(d)) x envs x steps of one launch; '
                                  'the plugin phases are latency / issue bound, `step_kernel` is the step kernel alone'},
+            'valu': _valu('k_closed', B * steps_per_launch / (launch_us * 1e-6)),
             'episode_stats': {'envs': int(stats.shape[0]), 'running_dynamic_collisions': int(stats[:, 3].sum()),
                               'mean_cells_discovered': float(stats[:, 6].double().mean())},
         }
