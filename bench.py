@@ -150,7 +150,9 @@ def _valu(kernel, env_steps_per_s_per_gpu):
     ceiling = N_SIMD * CLOCK_HZ / busy
     return {'insts_per_env_step': k.get('valu_insts_per_env_step'), 'salu_insts_per_env_step': k.get('salu_insts_per_env_step'),
             'busy_cycles_per_env_step': busy, 'ceiling_env_steps_per_s': ceiling, 'frac': env_steps_per_s_per_gpu / ceiling,
-            'note': 'issue ceiling of this instruction stream = 1024 SIMDs x 2.4 GHz / vector-pipe cycles per env-step (PMC)'}
+            'note': 'issue ceiling of this instruction stream = 1024 SIMDs x 2.4 GHz / vector-pipe cycles per env-step (PMC: per-wave '
+                    'issue cycles, ~4 per instruction; fp64 needs all 4, two waves\' int / f32 instructions can overlap on the SIMD-32, '
+                    'so the true ceiling lies between this figure and twice it)'}
 
 
 def _pmc(key):
