@@ -28,9 +28,10 @@ def _random_cfg(rng):
 
 
 N_SEEDS = int(os.environ.get('D2D_RANDOM_SEEDS', '48'))      # a soak run sets this higher
+SEED_BASE = int(os.environ.get('D2D_RANDOM_BASE', '0'))      # ... and moves on to fresh configurations
 
 
-@pytest.mark.parametrize('seed', range(N_SEEDS))
+@pytest.mark.parametrize('seed', range(SEED_BASE, SEED_BASE + N_SEEDS))
 def test_random_closed_loop_matches_oracle(pkg, hip, oracle, seed):
     rng = np.random.RandomState(1000 + seed)
     kw = _random_cfg(rng)
