@@ -211,7 +211,9 @@ struct SearchLds {
 #define D2D_SEARCH_LDS_NODES 512
 #define D2D_SEARCH_LDS_MAP 4096
 
-// Primitive.plan's search (traj_planner.py:128-218) by one wave.  Returns the number of waypoints written (0 = failure).
+// Primitive.plan's search (traj_planner.py:128-218) by one wave.  Returns the number of waypoints written, -1 = failure.
+// 0 is a success: the start node is the goal node (target within the search threshold of the start), the reference
+// returns True with an empty trajectory (traj_planner.py:158-160, 204-216).
 __device__ int plan_search(const d2d_cfg &c, const d2d_state &s, const d2d_plan &p, int e, int lane, const TrkView &T,
                            const SearchLds &S, const unsigned char *__restrict__ dm, double inv_scale) {
   const double H = p.horizon;
@@ -493,14 +495,14 @@ __device__ int plan_search(const d2d_cfg &c, const d2d_state &s, const d2d_plan 
     stat[2] = nn;
     if (overflow) stat[3] = 1;
   }
-  if (goal < 0 || overflow) return 0;
+  if (goal < 0 || overflow) return -1;
   SP_T(spa);
   // ---- :207-216: waypoints of every primitive on the path, start side first ----
   int depth = 0;
   for (int q = goal; q != 0 && depth <= 128; q = nd.link[q].x) depth += 1;  // bounded: a wave must always terminate
   if (depth * p.n_ts > p.traj_cap || depth > 128) {
     if (lane == 0) stat[3] = 1;
-    return 0;
+    return -1;
   }
   if (lane == 0) {
     int q = goal;
@@ -678,10 +680,10 @@ __device__ __forceinline__ void plan_env_search(const d2d_cfg &c, const d2d_stat
   // spends its time on; its wave shares the SIMD with three others that mostly run throughput phases.  Raised issue
   // priority lets it go first whenever it is ready (0.78 ms -> its stand-alone 0.46 ms is the range at stake).
   __builtin_amdgcn_s_setprio(3);
-  const int stored = plan_search(c, s, p, e, lane, T, S, dm, inv_scale);
+  const int found = plan_search(c, s, p, e, lane, T, S, dm, inv_scale);
   __builtin_amdgcn_s_setprio(0);
   wave_sync_global();
-  plan_emit(s, p, e, lane, 0, stored, stored > 0 ? 1 : 0);
+  plan_emit(s, p, e, lane, 0, found > 0 ? found : 0, found >= 0 ? 1 : 0);
 }
 
 // replan_check + plan + head waypoint of env e by one wave; `base`: plan_wave_bytes() bytes of LDS

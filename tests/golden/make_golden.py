@@ -260,7 +260,14 @@ def gen_closed():
         'closed_oxford_two_targets': dict(agent_number=6, agent_radius=10, agent_max_speed=20, map_id=9,
                                           target_list=[[250, 250], [450, 60]]),
     }
+    # the first target lies within the search threshold of the start: the start node is the goal node, Primitive.plan
+    # returns True with an EMPTY trajectory (traj_planner.py:158-160, 204-216), the drone stays and the goal test passes
+    cases['closed_oxford_goal_at_start'] = dict(agent_number=10, agent_radius=12, agent_max_speed=20, map_id=11,
+                                                target_list=[[47, 55], [122, 113]])
+    only = sys.argv[2:] if len(sys.argv) > 2 and sys.argv[1] == 'closed' else None
     for name, kw in cases.items():
+        if only and name not in only:
+            continue
         p = make_params(gaze_method='Oxford', planner='Primitive', **kw)
         save(name, run_trace(p, 400, policy='Oxford'))
 

@@ -119,5 +119,6 @@ TRACES_NOMOVE = ['nomove_n10_const', 'nomove_n10_rand_map0', 'nomove_n10_rand_ma
 TRACES_PLANNED = ['readme_oxford_primitive', 'lookahead_primitive_n30_map0', 'lookahead_primitive_n30_map3',
                   'deadlock_primitive']
 TRACES_CLOSED = ['closed_oxford_n20_map0', 'closed_oxford_n20_map5', 'closed_oxford_pillars_map2', 'closed_oxford_pillars_map6',
-                 'closed_oxford_slow_drone', 'closed_oxford_fast_drone', 'closed_oxford_fov120', 'closed_oxford_two_targets']
+                 'closed_oxford_slow_drone', 'closed_oxford_fast_drone', 'closed_oxford_fov120', 'closed_oxford_two_targets',
+                 'closed_oxford_goal_at_start']
 ALL_TRACES = TRACES_NOMOVE + TRACES_PLANNED + TRACES_CLOSED
