@@ -27,6 +27,21 @@ def _random_cfg(rng):
     return kw
 
 
+def _wide_cfg(seed, kw):
+    """Seeds from 20000 on also vary what the first family keeps at its default: the map size (non-square, and large
+    enough that the search probes the explored map in HBM instead of its LDS copy), the drone's radius, acceleration
+    limit (other primitive sets) and yaw rate."""
+    r2 = np.random.RandomState(500000 + seed)
+    kw = dict(kw)
+    kw.pop('static_map', None)                       # the label maps are 500 x 500
+    if r2.rand() < 0.6:
+        kw['map_size'] = [int(v) for v in r2.choice([500, 600, 700, 800, 1000], 2)]
+    kw['drone_radius'] = int(r2.choice([5, 10, 10, 15]))
+    kw['drone_max_acceleration'] = int(r2.choice([20, 40, 40, 60]))
+    kw['drone_max_yaw_speed'] = int(r2.choice([40, 80, 80, 120]))
+    return kw
+
+
 N_SEEDS = int(os.environ.get('D2D_RANDOM_SEEDS', '48'))      # a soak run sets this higher
 SEED_BASE = int(os.environ.get('D2D_RANDOM_BASE', '0'))      # ... and moves on to fresh configurations
 
@@ -35,6 +50,8 @@ SEED_BASE = int(os.environ.get('D2D_RANDOM_BASE', '0'))      # ... and moves on 
 def test_random_closed_loop_matches_oracle(pkg, hip, oracle, seed):
     rng = np.random.RandomState(1000 + seed)
     kw = _random_cfg(rng)
+    if seed >= 20000:
+        kw = _wide_cfg(seed, kw)
     B, T, chunk = int(rng.choice([3, 5, 8])), 160, int(rng.choice([5, 9, 16]))
     try:
         dev, ref = _pair(pkg, hip, oracle, B, **kw)
