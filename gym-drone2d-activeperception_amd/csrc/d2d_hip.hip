@@ -295,7 +295,7 @@ __device__ __forceinline__ void tile_rows2(const Tile &ta, unsigned char *la, co
   }
   {
     const int j = tb.j0 + col, jc = min(max(j, 0), H - 1);
-    const bool jok = j >= 0 && j < H;
+    const bool jok = col < tb.cols && j >= 0 && j < H;
 #pragma unroll
     for (int t = 0; t < MAXB; ++t) {
       const int r = 2 * t + half, i = tb.i0 + r;
@@ -316,7 +316,7 @@ __device__ __forceinline__ void tile_rows2(const Tile &ta, unsigned char *la, co
 #pragma unroll
   for (int t = 0; t < MAXB; ++t) {
     const int r = 2 * t + half;
-    if (r < tb.rows) lb[r * tb.cols + col] = vb[t];
+    if (r < tb.rows && col < tb.cols) lb[r * tb.cols + col] = vb[t];  // tiles narrower than 32 columns: crop edge L < 32
   }
   if (tb.cols > 32 && lane < tb.rows) lb[lane * tb.cols + 32] = vc;
 }

@@ -293,7 +293,28 @@ def gen_live(outdir, seed0, count):
         save(f'live_oxford_{seed0 + k}', run_trace(p, 120, policy='Oxford'))
 
 
+def gen_short_view():
+    """Short view depths: a 17 x 17 / 21 x 21 local map (L = 4 * (depth // scale) + 1 < 32) and a ray window of a few
+    cells -- the geometry the device's row-mapped tile loader mishandled until the random soak found it."""
+    rng = np.random.RandomState(777)
+    p = make_params(planner='NoMove', agent_number=8, agent_radius=25, agent_max_speed=30, map_id=21)
+    p.drone_view_depth = 40
+    p.drone_view_range = 120
+    T = 90
+    tele, cur = [], (250, 250)
+    for t in range(T):              # a new pose every sixth step (the drone of a NoMove run stays where it is put)
+        if t % 6 == 0:
+            cur = (int(rng.randint(15, 485)), int(rng.randint(15, 485)))
+        tele.append(cur)
+    save('nomove_short_view_d40', run_trace(p, T, actions=rng.uniform(-1, 1, T), teleport=tele, stop_on_done=False))
+    p = make_params(gaze_method='Oxford', planner='Primitive', agent_number=10, agent_radius=12, agent_max_speed=20, map_id=22)
+    p.drone_view_depth = 50
+    save('closed_oxford_short_view_d50', run_trace(p, 300, policy='Oxford'))
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == 'short_view':
+        return gen_short_view()
     if len(sys.argv) > 1 and sys.argv[1] == 'live':
         return gen_live(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]))
     if len(sys.argv) > 1 and sys.argv[1] == 'closed':

@@ -39,6 +39,8 @@ def _wide_cfg(seed, kw):
     kw['drone_radius'] = int(r2.choice([5, 10, 10, 15]))
     kw['drone_max_acceleration'] = int(r2.choice([20, 40, 40, 60]))
     kw['drone_max_yaw_speed'] = int(r2.choice([40, 80, 80, 120]))
+    if seed >= 30000:                                # short views: local map edge 4 * (depth // 10) + 1 < 32
+        kw['drone_view_depth'] = int(r2.choice([30, 40, 50, 60]))
     return kw
 
 

@@ -1,0 +1,73 @@
+"""Randomised parity of the fused step alone (run with -m gpu): seeded random configurations -- agent count / radius /
+speed, pillars, label maps, map size and scale, view cone, drone radius -- with random gaze actions, teleported drones
+(the external mutation API, validation_speed.py:135-138) and random external planner results (follow / brake branches),
+HIP vs the oracle, every field of the state bit for bit after every step."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from test_gpu_vs_oracle import _assert_same, _pair
+
+pytestmark = pytest.mark.gpu
+
+N_SEEDS = int(os.environ.get('D2D_RANDOM_SEEDS', '32'))      # a soak run sets this higher
+SEED_BASE = int(os.environ.get('D2D_RANDOM_BASE', '0'))
+
+
+def _cfg(rng):
+    kw = dict(agent_number=int(rng.choice([0, 1, 3, 10, 10, 17, 30, 33, 64, 65, 120])),
+              agent_radius=int(rng.choice([-1, 5, 8, 10, 12, 15, 18, 25])),
+              agent_max_speed=int(rng.choice([4, 10, 20, 30, 40, 60])), map_id=int(rng.randint(0, 100000)),
+              pillar_number=int(rng.choice([0, 0, 3, 6, 9])), drone_view_range=int(rng.choice([45, 60, 90, 90, 120, 200, 360])),
+              drone_view_depth=int(rng.choice([40, 60, 80, 80, 100, 150])), drone_radius=int(rng.choice([5, 10, 10, 15])),
+              drone_max_yaw_speed=int(rng.choice([40, 80, 80, 160])))
+    r = rng.rand()
+    if r < 0.25:
+        kw['static_map'] = str(rng.choice(['maps/obstacle_map.npy', 'maps/shaped_obstacle_map.npy', 'maps/random_map_0.npy']))
+    elif r < 0.55:
+        kw['map_size'] = [int(v) for v in rng.choice([300, 500, 640, 800, 1000, 1300], 2)]
+        if rng.rand() < 0.3:
+            kw['map_scale'] = 20
+    w, h = kw.get('map_size', [500, 500])
+    kw['init_pos'] = [int(rng.randint(40, w - 40)), int(rng.randint(40, h - 40))]
+    kw['target_list'] = [[int(rng.randint(40, w - 40)), int(rng.randint(40, h - 40))] for _ in range(int(rng.randint(1, 4)))]
+    if rng.rand() < 0.2:
+        kw['max_flight_time'] = 2
+    # the reference places agents and pillars by rejection sampling without a bound: keep the draw feasible
+    r = 15 if kw['agent_radius'] == -1 else kw['agent_radius'] + 2
+    while kw['agent_number'] * (2 * r) ** 2 > 0.2 * (w - 40) * (h - 40):
+        kw['agent_number'] //= 2
+    if min(w, h) < 500:
+        kw['pillar_number'] = 0
+    return kw
+
+
+@pytest.mark.parametrize('seed', range(SEED_BASE, SEED_BASE + N_SEEDS))
+def test_random_step_matches_oracle(pkg, hip, oracle, seed):
+    rng = np.random.RandomState(7000 + seed)
+    kw = _cfg(rng)
+    B, T = int(rng.choice([2, 5, 9])), 24
+    external = bool(rng.rand() < 0.5)
+    dev, ref = _pair(pkg, hip, oracle, B, planner='Primitive' if external else 'NoMove', **kw)
+    W, H = dev.cfg.W_px, dev.cfg.H_px
+    for t in range(T):
+        a = rng.uniform(-1, 1, B)
+        if rng.rand() < 0.2:       # teleport, sometimes right onto the border cells
+            lo = 1 if rng.rand() < 0.3 else 15
+            xy = np.stack([rng.randint(lo, W - lo, B), rng.randint(lo, H - lo, B)], 1).astype(np.float64)
+            if rng.rand() < 0.3:
+                xy += rng.choice([0.0, 0.25, 0.5], (B, 2))
+            for env in (dev, ref):
+                env.state.drone[:, :2] = torch.from_numpy(xy).to(env.device)
+        if external:
+            ok = rng.rand(B) < 0.7
+            valid = ok & (rng.rand(B) < 0.8)
+            wp = np.concatenate([np.stack([rng.uniform(12, W - 12, B), rng.uniform(12, H - 12, B)], 1).round()
+                                 + rng.choice([0.0, 0.5], (B, 2)), rng.uniform(-40, 40, (B, 2)), np.zeros((B, 2))], axis=1)
+            for env in (dev, ref):
+                env.set_plan(ok, valid, wp)
+        dev.step(a)
+        ref.step(a)
+        _assert_same(dev, ref, f'seed {seed} {kw} external={external} step {t + 1}')
