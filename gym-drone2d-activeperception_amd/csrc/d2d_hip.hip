@@ -1455,7 +1455,7 @@ int check(const d2d_cfg *c, const d2d_state *s) {
     return fail(-4, "map_scale must be an integer >= 2 (scale 1 never advances a ray, utils.py:621)");
   if (!(c->depth > 0) || !(c->dt > 0)) return fail(-1, "bad depth / dt");
   if (c->kf_enabled && (!s->kf || !s->kf_len)) return fail(-1, "kf_enabled without kf buffers");
-  if (c->sigma != 0.0 && c->kf_enabled && !s->noise) return fail(-1, "var_cam != 0 needs the noise input");
+  if (c->sigma != 0.0 && c->kf_enabled && c->N > 0 && !s->noise) return fail(-1, "var_cam != 0 needs the noise input");
   if (!s->agents || !s->agent_unit || !s->dyn_prev || !s->gt || !s->dmap || !s->drone || !s->target || !s->targets ||
       !s->counters || !s->active || !s->hit || !s->newly || !s->flags || !s->obs_local || !s->obs_yaw)
     return fail(-1, "null state pointer");

@@ -50,6 +50,10 @@ def test_random_step_matches_oracle(pkg, hip, oracle, seed):
     kw = _cfg(rng)
     B, T = int(rng.choice([2, 5, 9])), 24
     external = bool(rng.rand() < 0.5)
+    r2 = np.random.RandomState(900000 + seed)          # drawn apart so that the configurations above keep their seeds
+    mode = str(r2.choice(['fused', 'fused', 'split', 'stages']))   # device entry points; the oracle always runs the fused step
+    if r2.rand() < 0.3:
+        kw['var_cam'] = int(r2.choice([1, 2]))          # measurement noise: the draws are an input (utils.py:605)
     dev, ref = _pair(pkg, hip, oracle, B, planner='Primitive' if external else 'NoMove', **kw)
     W, H = dev.cfg.W_px, dev.cfg.H_px
     for t in range(T):
@@ -68,6 +72,18 @@ def test_random_step_matches_oracle(pkg, hip, oracle, seed):
                                  + rng.choice([0.0, 0.5], (B, 2)), rng.uniform(-40, 40, (B, 2)), np.zeros((B, 2))], axis=1)
             for env in (dev, ref):
                 env.set_plan(ok, valid, wp)
-        dev.step(a)
+        if kw.get('var_cam'):
+            noise = r2.standard_normal((B, dev.cfg.N, 2))
+            dev.set_noise(noise)
+            ref.set_noise(noise)
+        if mode == 'fused':
+            dev.step(a)
+        elif mode == 'split':
+            dev.perceive()
+            dev.act(a)
+        else:
+            dev._set_action(a)
+            for b in range(8):
+                dev.backend.run_stages(dev.cfg, dev._st, 1 << b)
         ref.step(a)
-        _assert_same(dev, ref, f'seed {seed} {kw} external={external} step {t + 1}')
+        _assert_same(dev, ref, f'seed {seed} {kw} external={external} mode={mode} step {t + 1}')
