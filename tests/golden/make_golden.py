@@ -272,7 +272,7 @@ def gen_closed():
         save(name, run_trace(p, 400, policy='Oxford'))
 
 
-def gen_live(outdir, seed0, count):
+def gen_live(outdir, seed0, count, wide=False):
     """Random closed-loop Oxford + Primitive episodes of the live reference into `outdir` (not committed: the
     build-container-only test tests/test_oracle_vs_live_reference.py replays them through the oracle)."""
     global OUT
@@ -289,6 +289,20 @@ def gen_live(outdir, seed0, count):
             kw['target_list'] = [[int(rng.randint(40, 460)), int(rng.randint(40, 460))], [int(rng.randint(40, 460)), int(rng.randint(40, 460))]]
         if rng.rand() < 0.3:
             kw['init_pos'] = [int(rng.randint(40, 460)), int(rng.randint(40, 460))]
+        if wide:    # what the family above keeps at its default: map size, drone radius / acceleration / yaw rate, short views,
+            #         a first target next to the start (Primitive.plan succeeds with an empty trajectory)
+            kw.pop('static_map', None)
+            if rng.rand() < 0.5:
+                kw['map_size'] = [int(v) for v in rng.choice([500, 600, 700, 800, 1000], 2)]
+            kw['drone_radius'] = int(rng.choice([5, 10, 10, 15]))
+            kw['drone_max_acceleration'] = int(rng.choice([20, 40, 40, 60]))
+            kw['drone_max_yaw_speed'] = int(rng.choice([40, 80, 80, 120]))
+            if rng.rand() < 0.5:
+                kw['drone_view_depth'] = int(rng.choice([30, 40, 50, 60]))
+            if rng.rand() < 0.15:
+                x0, y0 = kw.get('init_pos', [50, 50])
+                kw['target_list'] = [[x0 + int(rng.randint(-6, 7)), y0 + int(rng.randint(-6, 7))],
+                                     [int(rng.randint(40, 460)), int(rng.randint(40, 460))]]
         p = make_params(gaze_method='Oxford', planner='Primitive', **kw)
         save(f'live_oxford_{seed0 + k}', run_trace(p, 120, policy='Oxford'))
 
@@ -316,7 +330,7 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == 'short_view':
         return gen_short_view()
     if len(sys.argv) > 1 and sys.argv[1] == 'live':
-        return gen_live(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]))
+        return gen_live(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), wide=len(sys.argv) > 5 and sys.argv[5] == 'wide')
     if len(sys.argv) > 1 and sys.argv[1] == 'closed':
         return gen_closed()
     if len(sys.argv) > 1 and sys.argv[1] == 'sweep':

@@ -87,3 +87,34 @@ def test_random_step_matches_oracle(pkg, hip, oracle, seed):
                 dev.backend.run_stages(dev.cfg, dev._st, 1 << b)
         ref.step(a)
         _assert_same(dev, ref, f'seed {seed} {kw} external={external} mode={mode} step {t + 1}')
+
+
+N_ROLL = max(8, N_SEEDS // 4)
+
+
+@pytest.mark.parametrize('seed', range(SEED_BASE, SEED_BASE + N_ROLL))
+def test_random_rollout_matches_oracle(pkg, hip, oracle, seed):
+    """d2d_rollout (the survivability sweeps' inner loop, glob_survivability_calculator.py:31-37): T queued steps with a
+    pinned drone position and per-step collision rows, optionally over several streams, then a masked reset."""
+    rng = np.random.RandomState(31000 + seed)
+    kw = _cfg(rng)
+    B, T = int(rng.choice([3, 7, 12])), int(rng.choice([6, 15]))
+    dev, ref = _pair(pkg, hip, oracle, B, **kw)
+    W, H = dev.cfg.W_px, dev.cfg.H_px
+    acts = rng.uniform(-1, 1, (T, B))
+    pin = np.stack([rng.randint(15, W - 15, B), rng.randint(15, H - 15, B)], 1).astype(np.float64) if rng.rand() < 0.7 else None
+    coll = bool(rng.rand() < 0.7)
+    streams = int(rng.choice([1, 1, 2, 3]))
+    cd = dev.rollout(acts, pin=pin, collisions=coll, streams=streams)
+    cr = ref.rollout(acts, pin=pin, collisions=coll)
+    dev.sync()
+    tag = f'seed {seed} {kw} B={B} T={T} pin={pin is not None} coll={coll} streams={streams}'
+    if coll:
+        assert torch.equal(cd.cpu(), cr), tag
+    _assert_same(dev, ref, tag + ' after rollout')
+    mask = torch.from_numpy((rng.rand(B) < 0.5).astype(np.uint8))
+    dev.reset(mask)
+    ref.reset(mask)
+    dev.step(acts[0])
+    ref.step(acts[0])
+    _assert_same(dev, ref, tag + ' step after masked reset')

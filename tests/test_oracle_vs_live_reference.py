@@ -30,3 +30,22 @@ def live_traces(tmp_path_factory):
 @pytest.mark.parametrize('k', range(N_EPISODES))
 def test_oracle_reproduces_live_reference_episode(pkg, oracle, live_traces, k):
     _closed_loop(pkg, oracle, live_traces[k])
+
+
+N_WIDE = 6
+
+
+@pytest.fixture(scope='module')
+def live_traces_wide(tmp_path_factory):
+    """The wider family: map sizes, drone radius / acceleration limit / yaw rate, short views, a target next to the start."""
+    out = str(tmp_path_factory.mktemp('livewide'))
+    subprocess.check_call([sys.executable, os.path.join(ROOT, 'tests', 'golden', 'make_golden.py'), 'live', out, '9100', str(N_WIDE), 'wide'],
+                          stdout=subprocess.DEVNULL)
+    files = sorted(glob.glob(os.path.join(out, 'live_oxford_*.npz')))
+    assert len(files) == N_WIDE
+    return files
+
+
+@pytest.mark.parametrize('k', range(N_WIDE))
+def test_oracle_reproduces_live_reference_episode_wide(pkg, oracle, live_traces_wide, k):
+    _closed_loop(pkg, oracle, live_traces_wide[k])
