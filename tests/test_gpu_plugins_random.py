@@ -56,7 +56,17 @@ def test_random_closed_loop_matches_oracle(pkg, hip, oracle, seed):
         kw = _wide_cfg(seed, kw)
     B, T, chunk = int(rng.choice([3, 5, 8])), 160, int(rng.choice([5, 9, 16]))
     try:
-        dev, ref = _pair(pkg, hip, oracle, B, **kw)
+        if seed >= 40000:      # the other plugin combinations of the device path (the persistent kernel's non-split loop,
+            #                    the planner under a constant gaze action)
+            from drone2d_amd import vec_env
+            from test_gpu_vs_oracle import _worlds
+            kw = _wide_cfg(seed, kw)
+            planner, gaze = [('NoMove', 'Oxford'), ('Primitive', 'Rotating'), ('Primitive', 'NoControl'), ('NoMove', 'Rotating')][seed % 4]
+            p = pkg.Params(planner=planner, gaze_method=gaze, **kw)
+            ref = vec_env.VecDrone2DEnv(p, B, backend=oracle, planner=planner, device_plugins=True, gaze=gaze)
+            dev = vec_env.VecDrone2DEnv(p, B, backend=hip, planner=planner, device_plugins=True, gaze=gaze, worlds=_worlds(ref))
+        else:
+            dev, ref = _pair(pkg, hip, oracle, B, **kw)
     except NotImplementedError as ex:       # e.g. a view range this host's arccos window cannot describe
         pytest.skip(str(ex))
     mode = dict(auto_reset=True) if seed % 3 else dict(freeze_done=True)
