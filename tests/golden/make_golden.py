@@ -272,7 +272,7 @@ def gen_closed():
         save(name, run_trace(p, 400, policy='Oxford'))
 
 
-def gen_live(outdir, seed0, count, wide=False):
+def gen_live(outdir, seed0, count, wide=False, scale20=False):
     """Random closed-loop Oxford + Primitive episodes of the live reference into `outdir` (not committed: the
     build-container-only test tests/test_oracle_vs_live_reference.py replays them through the oracle)."""
     global OUT
@@ -299,6 +299,8 @@ def gen_live(outdir, seed0, count, wide=False):
             kw['drone_max_yaw_speed'] = int(rng.choice([40, 80, 80, 120]))
             if rng.rand() < 0.5:
                 kw['drone_view_depth'] = int(rng.choice([30, 40, 50, 60]))
+            if scale20:
+                kw['map_scale'] = 20
             if rng.rand() < 0.15:
                 x0, y0 = kw.get('init_pos', [50, 50])
                 kw['target_list'] = [[x0 + int(rng.randint(-6, 7)), y0 + int(rng.randint(-6, 7))],
@@ -330,7 +332,8 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == 'short_view':
         return gen_short_view()
     if len(sys.argv) > 1 and sys.argv[1] == 'live':
-        return gen_live(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), wide=len(sys.argv) > 5 and sys.argv[5] == 'wide')
+        return gen_live(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), wide=len(sys.argv) > 5 and sys.argv[5] in ('wide', 'wide20'),
+                        scale20=len(sys.argv) > 5 and sys.argv[5] == 'wide20')
     if len(sys.argv) > 1 and sys.argv[1] == 'closed':
         return gen_closed()
     if len(sys.argv) > 1 and sys.argv[1] == 'sweep':

@@ -39,6 +39,14 @@ def _wide_cfg(seed, kw):
     kw['drone_radius'] = int(r2.choice([5, 10, 10, 15]))
     kw['drone_max_acceleration'] = int(r2.choice([20, 40, 40, 60]))
     kw['drone_max_yaw_speed'] = int(r2.choice([40, 80, 80, 120]))
+    if 50000 <= seed < 60000:                        # map scale 20 (the reference mixes map_scale and a literal 10), many agents
+        kw['map_scale'] = 20
+        if r2.rand() < 0.3:
+            kw['agent_number'] = int(r2.choice([40, 64, 65, 100]))
+            kw['agent_radius'] = int(r2.choice([5, 8]))
+            w, h = kw.get('map_size', [500, 500])
+            while kw['agent_number'] * (2 * (kw['agent_radius'] + 2)) ** 2 > 0.2 * (w - 40) * (h - 40):
+                kw['agent_number'] //= 2
     if seed >= 30000:                                # short views: local map edge 4 * (depth // 10) + 1 < 32
         kw['drone_view_depth'] = int(r2.choice([30, 40, 50, 60]))
     return kw
