@@ -57,8 +57,12 @@ class BatchState:
         B = self.cfg.B
         assert len(worlds) == B
         for name in ('agents', 'agent_unit', 'dyn_prev', 'gt', 'dmap', 'drone', 'target', 'targets', 'counters'):
-            arr = np.stack([w[name] for w in worlds])
-            self.t[name].copy_(torch.from_numpy(arr).to(self.t[name].dtype))
+            # in slices of <= 256 MB of host staging: a config-5 shard is 32768 grids of 640 x 640 cells = 13.4 GB per field
+            per = max(1, int(np.asarray(worlds[0][name]).nbytes))
+            step = max(1, (256 << 20) // per)
+            for c0 in range(0, B, step):
+                arr = np.stack([w[name] for w in worlds[c0:c0 + step]])
+                self.t[name][c0:c0 + step].copy_(torch.from_numpy(arr).to(self.t[name].dtype))
         self.t['active'].zero_()
         self._kf_defaults()
 

@@ -25,9 +25,22 @@ for t in range(4):
 print('parity ok: 4 envs x 4 steps, R =', dev.cfg.R, 'grid', dev.cfg.W, 'x', dev.cfg.H)
 B = int(os.environ.get('B', 2048))
 big = vec_env.VecDrone2DEnv(p, B, backend=hip, worlds=[worlds[i % 4] for i in range(B)])
-acts = torch.rand(40, B, dtype=torch.float64, device='cuda') * 2 - 1
+acts = (torch.rand(40, 4, dtype=torch.float64, device='cuda') * 2 - 1).repeat(1, B // 4 + 1)[:, :B].contiguous()   # env e acts like env e % 4
 for t in range(5): big.step(acts[t])
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for t in range(5, 35): big.step(acts[t])
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 30
 print(f'B={B}: {dt * 1e6:.1f} us per step, {B / dt:.3e} env-steps/s; grids {2 * B * 640 * 640 / 2**30:.2f} GiB')
+# size-independent property at the full size: the replicas of a world (same actions) stay identical, bit for bit
+if B % 4 == 0 and B > 4:
+    for name in ('gt', 'dmap', 'drone', 'agents', 'counters', 'kf', 'obs_local', 'hit'):
+        x = big.state.t[name]
+        x = x.view(B // 4, 4, *x.shape[1:])
+        assert bool((x == x[:1]).all()), name
+    ref4 = vec_env.VecDrone2DEnv(p, 4, backend=hip, worlds=worlds)
+    for t in range(35): ref4.step(acts[t, :4])
+    torch.cuda.synchronize()
+    for name in ('gt', 'dmap', 'drone', 'agents', 'counters', 'kf', 'obs_local', 'hit'):
+        assert torch.equal(big.state.t[name][:4], ref4.state.t[name]), name
+    print(f'replica property ok at B={B}: every env equals the 4-env run of its world; device memory in use '
+          f'{torch.cuda.memory_allocated() / 2**30:.1f} GiB')
