@@ -30,6 +30,13 @@
 #include <string.h>
 #include <type_traits>
 
+// Device pass: the pointers of d2d_state / d2d_plan are global-address-space pointers.  The persistent kernel reads them out
+// of a struct in memory; as plain (generic) pointers every access through them is a `flat_*` instruction, which counts on
+// vmcnt AND lgkmcnt -- each LDS hand-off wait then also waits for all global traffic in flight -- and takes a 64-bit VGPR
+// address.  (Kernel ARGUMENTS are inferred global by the compiler; loaded pointers are not.)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define D2D_AS __attribute__((address_space(1)))
+#endif
 #include "../../include/d2d.h"
 
 #define D2D_TAN_QUAL __device__ __forceinline__
@@ -1335,18 +1342,25 @@ __host__ __device__ inline int closed_wave_bytes(const d2d_cfg &c, const d2d_pla
   return (b + 15) & ~15;
 }
 
-// function arguments arrive in VGPRs; these are wave-uniform by construction, say so
-__device__ __forceinline__ const ClosedArgs *uniform_ptr(const ClosedArgs *p) {
+// function arguments arrive in VGPRs; these are wave-uniform by construction, say so -- and say that the bundle lives in
+// device memory nobody writes during the launch (constant address space): its fields then come through scalar loads
+// instead of per-lane `flat_load`s
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef const ClosedArgs __attribute__((address_space(4))) *ArgsPtr;
+#else
+typedef const ClosedArgs *ArgsPtr;  // the host pass only parses the device functions
+#endif
+__device__ __forceinline__ ArgsPtr uniform_ptr(const ClosedArgs *p) {
   const unsigned long long v = (unsigned long long)p;
   const unsigned int lo = __builtin_amdgcn_readfirstlane((unsigned int)v), hi = __builtin_amdgcn_readfirstlane((unsigned int)(v >> 32));
-  return (const ClosedArgs *)(((unsigned long long)hi << 32) | lo);
+  return (ArgsPtr)(((unsigned long long)hi << 32) | lo);
 }
 
 // The planner stage as two calls: the part every step runs (small: few registers to save), and the search, called
 // only when the trajectory is empty (a few percent of the steps).
 template <int SPEC>
 __device__ __attribute__((noinline)) int ph_plan_quick(const ClosedArgs *ap, int e_, int lds_off_) {
-  const ClosedArgs *__restrict__ a = uniform_ptr(ap);
+  const ArgsPtr a = uniform_ptr(ap);
   const int e = __builtin_amdgcn_readfirstlane(e_), lane = threadIdx.x & (WAVE - 1);
   char *base = d2d_lds + __builtin_amdgcn_readfirstlane(lds_off_);
   d2d_cfg c = a->c;
@@ -1358,7 +1372,7 @@ __device__ __attribute__((noinline)) int ph_plan_quick(const ClosedArgs *ap, int
 
 template <int SPEC>
 __device__ __attribute__((noinline)) void ph_plan_search(const ClosedArgs *ap, int e_, int lds_off_) {
-  const ClosedArgs *__restrict__ a = uniform_ptr(ap);
+  const ArgsPtr a = uniform_ptr(ap);
   const int e = __builtin_amdgcn_readfirstlane(e_), lane = threadIdx.x & (WAVE - 1);
   char *base = d2d_lds + __builtin_amdgcn_readfirstlane(lds_off_);
   d2d_cfg c = a->c;
@@ -1370,7 +1384,7 @@ __device__ __attribute__((noinline)) void ph_plan_search(const ClosedArgs *ap, i
 // gaze + the stages that follow it in one call (one set of callee-saved registers, one fence fewer per step)
 template <int SPEC, uint32_t STAGES>
 __device__ __attribute__((noinline)) void ph_gaze_stages(const ClosedArgs *ap, int e_, int lds_off_) {
-  const ClosedArgs *__restrict__ a = uniform_ptr(ap);
+  const ArgsPtr a = uniform_ptr(ap);
   const int e = __builtin_amdgcn_readfirstlane(e_), lane = threadIdx.x & (WAVE - 1);
   char *base = d2d_lds + __builtin_amdgcn_readfirstlane(lds_off_);
   d2d_cfg c = a->c;
@@ -1389,7 +1403,7 @@ __device__ __attribute__((noinline)) void ph_gaze_stages(const ClosedArgs *ap, i
 
 template <int SPEC, uint32_t STAGES>
 __device__ __attribute__((noinline)) void ph_stages(const ClosedArgs *ap, int e_, int lds_off_) {
-  const ClosedArgs *__restrict__ a = uniform_ptr(ap);
+  const ArgsPtr a = uniform_ptr(ap);
   const int e = __builtin_amdgcn_readfirstlane(e_), lane = threadIdx.x & (WAVE - 1);
   char *base = d2d_lds + __builtin_amdgcn_readfirstlane(lds_off_);
   d2d_cfg c = a->c;
@@ -1472,7 +1486,7 @@ int launch_stages(const d2d_cfg *c, const d2d_state *s, uint32_t stages, void *s
     return fail(-1, "external planner mode needs plan_ok / wp_valid / wp");
   if (c->B == 0) return 0;
   d2d_state st = *s;
-  if (!st.action) st.action = (const double *)st.drone;  // never dereferenced meaningfully without CONTROL
+  if (!st.action) st.action = (const double D2D_AS *)st.drone;  // never dereferenced meaningfully without CONTROL
 #ifndef D2D_NO_SPEC
   if (spec_default_matches(*c) && c->N > spec_ncap(2)) {
     const int wpb = pick_wpb(*c);
@@ -1625,8 +1639,8 @@ int d2d_rollout(const d2d_cfg *c, const d2d_state *s, int32_t nsteps, const doub
   if (!actions || nsteps < 0) return fail(-1, "rollout: bad arguments");
   d2d_state st = *s;
   for (int32_t t = 0; t < nsteps; ++t) {
-    st.action = actions + (size_t)t * c->B;
-    if (wp_steps) st.wp = wp_steps + (size_t)t * c->B * 6;
+    st.action = (const double D2D_AS *)(actions + (size_t)t * c->B);
+    if (wp_steps) st.wp = (const double D2D_AS *)(wp_steps + (size_t)t * c->B * 6);
     rc = launch_stages(c, &st, D2D_ST_ALL, stream, pin, coll_out ? coll_out + (size_t)t * c->B : nullptr);
     if (rc) return rc;
   }

@@ -115,6 +115,13 @@ extern "C" {
 #define D2D_DONE_FREEZE 2   /* stays as it ended: one episode per env, the terminal state is the result (main.py)  */
 
 /* Numeric mirror of the reference's Params (utils.py:65-106) plus derived constants. */
+/* Address space of the device pointers below.  Empty for every C / C++ user of this header (plain pointers, the ABI);
+ * the HIP translation unit sets it to the global address space for its device pass, so that a pointer read out of a
+ * struct in memory is known to be a global pointer (`global_*` instead of `flat_*` accesses).  Layout is unaffected. */
+#ifndef D2D_AS
+#define D2D_AS
+#endif
+
 typedef struct d2d_cfg {
   int32_t abi_version; /* D2D_ABI_VERSION */
   int32_t B;           /* envs in this shard */
@@ -143,31 +150,31 @@ typedef struct d2d_cfg {
 
 typedef struct d2d_state {
   /* ---- world state (read + written) ---- */
-  double *agents;      /* [B][D2D_AF][N] */
-  int32_t *agent_unit; /* [B][N]  int(radius // scale) (utils.py:533-534) */
-  int32_t *dyn_prev;   /* [B][N][3] cell block (cx, cy, half) that may hold DYNAMIC cells written for
+  double D2D_AS *agents;      /* [B][D2D_AF][N] */
+  int32_t D2D_AS *agent_unit; /* [B][N]  int(radius // scale) (utils.py:533-534) */
+  int32_t D2D_AS *dyn_prev;   /* [B][N][3] cell block (cx, cy, half) that may hold DYNAMIC cells written for
                           this agent last time: replaces the dynamic_idx list (utils.py:506,528-530) */
-  uint8_t *gt;         /* [B][W][H] ground-truth grid, env.map_gt.grid_map */
-  uint8_t *dmap;       /* [B][W][H] the drone's explored map, env.drone.map.grid_map */
-  double *drone;       /* [B][D2D_DF] */
-  double *target;      /* [B][2] planner.target[:2] */
-  double *targets;     /* [B][T][2] env.target_list */
-  int32_t *counters;   /* [B][D2D_CF] */
-  uint8_t *active;     /* [B][N] KalmanFilter.active (utils.py:182,273) */
-  double *kf;          /* [B][N][D2D_KF] or NULL when !kf_enabled */
-  int32_t *kf_len;     /* [B][N] len(tracker.ts) or NULL */
+  uint8_t D2D_AS *gt;         /* [B][W][H] ground-truth grid, env.map_gt.grid_map */
+  uint8_t D2D_AS *dmap;       /* [B][W][H] the drone's explored map, env.drone.map.grid_map */
+  double D2D_AS *drone;       /* [B][D2D_DF] */
+  double D2D_AS *target;      /* [B][2] planner.target[:2] */
+  double D2D_AS *targets;     /* [B][T][2] env.target_list */
+  int32_t D2D_AS *counters;   /* [B][D2D_CF] */
+  uint8_t D2D_AS *active;     /* [B][N] KalmanFilter.active (utils.py:182,273) */
+  double D2D_AS *kf;          /* [B][N][D2D_KF] or NULL when !kf_enabled */
+  int32_t D2D_AS *kf_len;     /* [B][N] len(tracker.ts) or NULL */
   /* ---- inputs of this step (read only) ---- */
-  const double *action;    /* [B] gaze action a in [-1, 1] (drone_v2.py:152,214) */
-  const uint8_t *plan_ok;  /* [B] planner.plan() result (drone_v2.py:197); NULL under NOMOVE */
-  const uint8_t *wp_valid; /* [B] trajectory non-empty at step_pos (utils.py:734); NULL under NOMOVE */
-  const double *wp;        /* [B][6] head waypoint: pos(2), vel(2), acc(2) (utils.py:735-738) */
-  const double *noise;     /* [B][N][2] standard normal draws for utils.py:605, or NULL (sigma must be 0) */
+  const double D2D_AS *action;    /* [B] gaze action a in [-1, 1] (drone_v2.py:152,214) */
+  const uint8_t D2D_AS *plan_ok;  /* [B] planner.plan() result (drone_v2.py:197); NULL under NOMOVE */
+  const uint8_t D2D_AS *wp_valid; /* [B] trajectory non-empty at step_pos (utils.py:734); NULL under NOMOVE */
+  const double D2D_AS *wp;        /* [B][6] head waypoint: pos(2), vel(2), acc(2) (utils.py:735-738) */
+  const double D2D_AS *noise;     /* [B][N][2] standard normal draws for utils.py:605, or NULL (sigma must be 0) */
   /* ---- outputs of this step (written) ---- */
-  uint8_t *hit;        /* [B][N] OR over rays of the per-ray hit lists (utils.py:598-599) */
-  int32_t *newly;      /* [B] newly_tracked (utils.py:606-607) */
-  uint8_t *flags;      /* [B][4] collision, dead_lock, freezing, done */
-  uint8_t *obs_local;  /* [B][L][L] obs['local_map'] (== obs['swep_map'], drone_v2.py:252-253) */
-  float *obs_yaw;      /* [B] obs['yaw_angle'] */
+  uint8_t D2D_AS *hit;        /* [B][N] OR over rays of the per-ray hit lists (utils.py:598-599) */
+  int32_t D2D_AS *newly;      /* [B] newly_tracked (utils.py:606-607) */
+  uint8_t D2D_AS *flags;      /* [B][4] collision, dead_lock, freezing, done */
+  uint8_t D2D_AS *obs_local;  /* [B][L][L] obs['local_map'] (== obs['swep_map'], drone_v2.py:252-253) */
+  float D2D_AS *obs_yaw;      /* [B] obs['yaw_angle'] */
 } d2d_state;
 
 
@@ -224,31 +231,31 @@ typedef struct d2d_plan {
   int64_t acos_key_lo;
   uint64_t acos_mask;
   /* ---- constant tables (read only) ---- */
-  const double *u_space;
-  const double *sample_t;
-  const double *traj_t;
-  const double *yaw_space;
-  const double *tobs_tab;
-  const int32_t *pw_leaf;
-  const int32_t *pw_prog;
-  const int32_t *pw_tree;    /* [pw_ntree] the additions of pw_prog level by level: n_levels, root id, level_start[n_levels + 1],
+  const double D2D_AS *u_space;
+  const double D2D_AS *sample_t;
+  const double D2D_AS *traj_t;
+  const double D2D_AS *yaw_space;
+  const double D2D_AS *tobs_tab;
+  const int32_t D2D_AS *pw_leaf;
+  const int32_t D2D_AS *pw_prog;
+  const int32_t D2D_AS *pw_tree;    /* [pw_ntree] the additions of pw_prog level by level: n_levels, root id, level_start[n_levels + 1],
                                 then (dst, left, right) per addition; ids 0..pw_nleaf-1 are the blocks (device only) */
-  const int32_t *pw_rowleaf; /* [W] the block that holds the first cell of grid row i (device only) */
-  const double *trk_radius0; /* [B][N] tracker radii of the initial world: the reset source of trk_radius */
+  const int32_t D2D_AS *pw_rowleaf; /* [W] the block that holds the first cell of grid row i (device only) */
+  const double D2D_AS *trk_radius0; /* [B][N] tracker radii of the initial world: the reset source of trk_radius */
   /* ---- per-env plugin state (read + written) ---- */
-  double *traj;         /* [B][traj_cap][4] planner.trajectory: position(2), velocity(2); accelerations are 0 */
-  int32_t *traj_hdr;    /* [B][2] index of the head waypoint, number of waypoints stored (len = stored - head) */
-  double *trk_radius;   /* [B][N] drone.trackers[k].radius (envs/drone_v2.py:46; back to agent_radius on archive) */
-  uint8_t *trk_prev;    /* [B][N] tracker.active as the planner stage last saw it (detects the archive) */
-  int32_t *seen_step;   /* [B][W][H] Oxford: number of the plan() call that last saw the cell, 0 = never */
+  double D2D_AS *traj;         /* [B][traj_cap][4] planner.trajectory: position(2), velocity(2); accelerations are 0 */
+  int32_t D2D_AS *traj_hdr;    /* [B][2] index of the head waypoint, number of waypoints stored (len = stored - head) */
+  double D2D_AS *trk_radius;   /* [B][N] drone.trackers[k].radius (envs/drone_v2.py:46; back to agent_radius on archive) */
+  uint8_t D2D_AS *trk_prev;    /* [B][N] tracker.active as the planner stage last saw it (detects the archive) */
+  int32_t D2D_AS *seen_step;   /* [B][W][H] Oxford: number of the plan() call that last saw the cell, 0 = never */
   /* ---- scratch of the search (contents meaningless between calls) ---- */
-  double *nodes;        /* [B][node_cap * D2D_NODE_F] search nodes; the field order inside an env's block is the
+  double D2D_AS *nodes;        /* [B][node_cap * D2D_NODE_F] search nodes; the field order inside an env's block is the
                            implementation's (the oracle keeps records, the HIP library planes) */
-  int32_t *hash;        /* [B][hash_cap] */
+  int32_t D2D_AS *hash;        /* [B][hash_cap] */
   void *launch_args;    /* >= D2D_LAUNCH_ARGS_BYTES of device memory where the persistent closed-loop launch parks its
                            arguments (NULL: d2d_closed_loop launches every stage of every step separately) */
   /* ---- diagnostics ---- */
-  int32_t *plan_stat;   /* [B][4] searches run, expansions of the last search, nodes of the last search,
+  int32_t D2D_AS *plan_stat;   /* [B][4] searches run, expansions of the last search, nodes of the last search,
                            capacity overflow flag (sticky; a search that overflowed reports failure) */
 } d2d_plan;
 

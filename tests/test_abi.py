@@ -41,7 +41,7 @@ def test_header_constants_match_ctypes_mirror(pkg):
     names = []
     for line in body.splitlines():
         line = line.split('/*')[0]
-        m = re.match(r'\s*(?:const\s+)?(int32_t|double|int64_t|uint64_t|uint8_t|void)\s+\*?\s*(\w+);', line)
+        m = re.match(r'\s*(?:const\s+)?(int32_t|double|int64_t|uint64_t|uint8_t|void)\s+(?:D2D_AS\s+)?\*?\s*(\w+);', line)
         if m:
             names.append(m.group(2))
     assert names == [f[0] for f in A.Plan._fields_]
