@@ -1430,52 +1430,25 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK, D2D_MIN_WAVES) void k_closed
   const bool split = a->p.planner == D2D_PLAN_PRIMITIVE;
   const int nsteps = a->nsteps;
   const bool freeze = a->on_done == D2D_DONE_FREEZE;
+  int nsearch = 0;
 #pragma unroll 1
   for (int t = 0; t < nsteps; ++t) {
     if (freeze && a->s.flags[(size_t)e * 4 + D2D_F_DONE] != 0) break;  // one episode per env: it stays as it ended
-#ifdef D2D_CLOSED_INLINE
     if (split) {
-      // experiment: gaze + perceive in the kernel body, every loop-invariant input laundered per iteration
-      unsigned int alo = __builtin_amdgcn_readfirstlane((unsigned int)(unsigned long long)a);
-      unsigned int ahi = __builtin_amdgcn_readfirstlane((unsigned int)((unsigned long long)a >> 32));
-      int e2 = __builtin_amdgcn_readfirstlane(e), off2 = __builtin_amdgcn_readfirstlane(off), lane2 = threadIdx.x & (WAVE - 1);
-      asm volatile("" : "+s"(alo), "+s"(ahi), "+s"(e2), "+s"(off2), "+v"(lane2));
-      {
-        const ArgsPtr a2 = (ArgsPtr)(((unsigned long long)ahi << 32) | alo);
-        char *base = d2d_lds + off2;
-        d2d_cfg c2 = a2->c;
-        if (SPEC != 0) spec_default_apply(c2);
-        gaze_env(c2, a2->s, a2->p, a2->init, a2->on_done == D2D_DONE_RESET, e2, lane2, base);
-        wave_sync_global();
-      }
-      asm volatile("" : "+s"(alo), "+s"(ahi), "+s"(e2), "+s"(off2), "+v"(lane2));
-      {
-        const ArgsPtr a2 = (ArgsPtr)(((unsigned long long)ahi << 32) | alo);
-        char *base = d2d_lds + off2;
-        d2d_cfg c2 = a2->c;
-        if (SPEC != 0) spec_default_apply(c2);
-        const Geom g = make_geom(c2, wpb, spec_ncap(SPEC));
-        const LdsView L = carve(base, g, c2.L);
-        EnvRegs r;
-        load_regs(a2->s, e2, r);
-        run_env(c2, a2->s, e2, lane2, D2D_ST_PERCEIVE, g, L, a2->s.action[e2], r);
-        if (lane2 == 0) store_regs(a2->s, e2, r);
-        wave_sync_global();
-      }
-      if (__builtin_amdgcn_readfirstlane(ph_plan_quick<SPEC>(a, e, off))) ph_plan_search<SPEC>(a, e, off);
-      ph_stages<SPEC, D2D_ST_ACT>(a, e, off);
-    } else {
-      ph_gaze_stages<SPEC, D2D_ST_ALL>(a, e, off);
-    }
-#else
-    if (split) {
+      // An env that searches often is the one the launch ends up waiting for (the worlds repeat, so it stays that env):
+      // past one search per 32 steps of this launch all its phases issue first on their SIMD.  Its chain is
+      // latency-bound, so the three waves it shares the SIMD with give up little.  (+4 % at 4096 envs; thresholds 16-64
+      // and levels 1-2 measure the same, level 3 -- the search's own -- less.)
+      if (nsearch * 32 > t + 16) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);
       ph_gaze_stages<SPEC, D2D_ST_PERCEIVE>(a, e, off);
-      if (__builtin_amdgcn_readfirstlane(ph_plan_quick<SPEC>(a, e, off))) ph_plan_search<SPEC>(a, e, off);
+      if (__builtin_amdgcn_readfirstlane(ph_plan_quick<SPEC>(a, e, off))) {
+        ph_plan_search<SPEC>(a, e, off);
+        nsearch += 1;
+      }
       ph_stages<SPEC, D2D_ST_ACT>(a, e, off);
     } else {
       ph_gaze_stages<SPEC, D2D_ST_ALL>(a, e, off);
     }
-#endif
   }
 }
 
