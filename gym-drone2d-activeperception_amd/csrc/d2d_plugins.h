@@ -130,11 +130,21 @@ __device__ __forceinline__ bool plan_is_free(const d2d_cfg &c, const d2d_plan &p
   const bool oy0 = (yl >= c.H_px) | (yl < 0.0), oy1 = (y >= c.H_px) | (y < 0.0), oy2 = (yr >= c.H_px) | (yr < 0.0);
   const bool wall = (ox0 | oy1 | (v0 == D2D_OCCUPIED)) | (ox1 | oy1 | (v1 == D2D_OCCUPIED)) | (ox2 | oy1 | (v2 == D2D_OCCUPIED)) |
                     (ox1 | oy0 | (v3 == D2D_OCCUPIED)) | (ox1 | oy2 | (v4 == D2D_OCCUPIED));
+  // Four trackers per round, loads first: one tracker per iteration pays the LDS latency once per tracker (the trip
+  // count is dynamic, the compiler does not pipeline it).  The planes are padded to a multiple of four entries.
   bool hit = false;
-  for (int q = 0; q < T.n; ++q) {
-    const double ex = T.mx[q] + t * T.vx[q], ey = T.my[q] + t * T.vy[q];  // estimate_pos, utils.py:220-223
-    const double dx = x - ex, dy = y - ey;
-    hit = hit | (__builtin_fma(dy, dy, dx * dx) <= T.lim_plan[q]);
+  for (int q = 0; q < T.n; q += 4) {
+    double mx[4], my[4], vx[4], vy[4], lim[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      mx[u] = T.mx[q + u]; my[u] = T.my[q + u]; vx[u] = T.vx[q + u]; vy[u] = T.vy[q + u]; lim[u] = T.lim_plan[q + u];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const double ex = mx[u] + t * vx[u], ey = my[u] + t * vy[u];  // estimate_pos, utils.py:220-223
+      const double dx = x - ex, dy = y - ey;
+      hit = hit | ((q + u < T.n) & (__builtin_fma(dy, dy, dx * dx) <= lim[u]));
+    }
   }
   return !wall && !hit;
 }
@@ -359,20 +369,38 @@ __device__ int plan_search(const d2d_cfg &c, const d2d_state &s, const d2d_plan 
         pcnt[lane] = 0;
         wave_sync_lds();
         const int npair = nv * p.n_sample;
-        for (int q0 = 0; q0 < npair; q0 += WAVE) {
-          const int q = q0 + lane;
-          if (q < npair) {
-            int pr, si, sia, sja;
-            fd_ns.divmod(q, pr, si);
-            fd_nu.divmod(plist[pr], sia, sja);
-            const double shx = S.us[sia] / 2, shy = S.us[sja] / 2;
-            const double t = S.st[2 * si], t2 = S.st[2 * si + 1];
-            const double sx = rint(__builtin_fma(t2, shx, px + t * vx)), sy = rint(__builtin_fma(t2, shy, py + t * vy));
-            const double tg = t + (double)citr * H;
-            const bool fr = lds_map ? plan_is_free(c, p, (const unsigned char *)S.map, T, sx, sy, tg, inv_scale)
-                                    : plan_is_free(c, p, dm, T, sx, sy, tg, inv_scale);
-            if (fr) atomicAdd(&pcnt[pr], 1);
+        // two rounds of pairs in flight (about ten primitives x eight samples = 80 pairs): each round is a chain of
+        // dependent LDS round trips (list -> tables -> map bytes -> counter), clamped indices keep both chains unconditional
+        for (int q0 = 0; q0 < npair; q0 += 2 * WAVE) {
+          int pr[2], sia[2], sja[2], si[2];
+          bool in[2], fr[2];
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const int q = q0 + u * WAVE + lane;
+            in[u] = q < npair;
+            fd_ns.divmod(in[u] ? q : 0, pr[u], si[u]);
           }
+          int pl[2];
+#pragma unroll
+          for (int u = 0; u < 2; ++u) pl[u] = plist[pr[u]];
+#pragma unroll
+          for (int u = 0; u < 2; ++u) fd_nu.divmod(pl[u], sia[u], sja[u]);
+          double ux[2], uy[2], tt[2], tt2[2];
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            ux[u] = S.us[sia[u]]; uy[u] = S.us[sja[u]]; tt[u] = S.st[2 * si[u]]; tt2[u] = S.st[2 * si[u] + 1];
+          }
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const double shx = ux[u] / 2, shy = uy[u] / 2;
+            const double sx = rint(__builtin_fma(tt2[u], shx, px + tt[u] * vx)), sy = rint(__builtin_fma(tt2[u], shy, py + tt[u] * vy));
+            const double tg = tt[u] + (double)citr * H;
+            fr[u] = lds_map ? plan_is_free(c, p, (const unsigned char *)S.map, T, sx, sy, tg, inv_scale)
+                            : plan_is_free(c, p, dm, T, sx, sy, tg, inv_scale);
+          }
+#pragma unroll
+          for (int u = 0; u < 2; ++u)
+            if (in[u] & fr[u]) atomicAdd(&pcnt[pr[u]], 1);
         }
         wave_sync_lds();
         if (ok) ok = pcnt[myrank] == p.n_sample;
@@ -646,10 +674,18 @@ __device__ __forceinline__ bool plan_env_quick(const d2d_cfg &c, const d2d_state
         // swep_map is uint8: the stored value is trunc(i * dt); a wall under a non-zero stored value forces the replan
         const int sv = ((int)ti) & 0xff;
         if (in && sv > 0 && dm[min(max(ci, 0), c.W - 1) * c.H + min(max(cj, 0), c.H - 1)] == D2D_OCCUPIED) bad = true;
-        for (int q = 0; q < nact; ++q) {
-          const double ex = T.mx[q] + ti * T.vx[q], ey = T.my[q] + ti * T.vy[q];
-          const double dx = ex - wx, dy = ey - wy;
-          if (__builtin_fma(dy, dy, dx * dx) <= T.lim_replan[q]) bad = true;
+        for (int q = 0; q < nact; q += 4) {  // four trackers per round, loads first (see plan_is_free)
+          double mx[4], my[4], vx[4], vy[4], lim[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            mx[u] = T.mx[q + u]; my[u] = T.my[q + u]; vx[u] = T.vx[q + u]; vy[u] = T.vy[q + u]; lim[u] = T.lim_replan[q + u];
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const double ex = mx[u] + ti * vx[u], ey = my[u] + ti * vy[u];
+            const double dx = ex - wx, dy = ey - wy;
+            bad = bad | ((q + u < nact) & (__builtin_fma(dy, dy, dx * dx) <= lim[u]));
+          }
         }
       }
     }
