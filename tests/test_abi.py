@@ -93,3 +93,21 @@ def test_product_never_touches_the_oracle():
             if f.endswith(('.py', '.hip', '.h', '.cpp', '.sh')):
                 txt = open(os.path.join(dp, f)).read()
                 assert 'liboracle' not in txt and 'oracle_lib' not in txt and 'd2d_oracle_' not in txt, f
+
+
+def test_header_is_plain_c_for_binders(tmp_path):
+    """include/d2d.h compiles as C99 and as C++ without any macro set (D2D_AS expands to nothing: plain pointers), and the
+    struct sizes are the ctypes mirror's."""
+    import shutil
+    import subprocess
+    if not shutil.which('gcc'):
+        pytest.skip('no gcc')
+    from drone2d_amd import _abi as A
+    src = tmp_path / 'hdr.c'
+    src.write_text('#include "include/d2d.h"\n#include <stdio.h>\n'
+                   'int main(void) { printf("%zu %zu %zu\\n", sizeof(d2d_cfg), sizeof(d2d_state), sizeof(d2d_plan)); return 0; }\n')
+    exe = tmp_path / 'hdr'
+    subprocess.check_call(['gcc', '-std=c99', '-Wall', '-Werror', '-pedantic', '-I', ROOT, str(src), '-o', str(exe)])
+    sizes = [int(v) for v in subprocess.check_output([str(exe)]).split()]
+    assert sizes == [C.sizeof(A.Cfg), C.sizeof(A.State), C.sizeof(A.Plan)]
+    subprocess.check_call(['g++', '-std=c++11', '-Wall', '-Werror', '-I', ROOT, '-x', 'c++', '-fsyntax-only', str(src)])
