@@ -413,13 +413,19 @@ __device__ int plan_search(const d2d_cfg &c, const d2d_state &s, const d2d_plan 
       const long long key = node_key(ex, ey, vex, vey);
       // ---- :192-202 for all successors of the batch at once ----
       int slot = -1;
+      long long slot_state = 0;  // state and cost of the node found, fetched in the same round trip as its key
+      double slot_cost = 0.0;
       if (ok) {
         unsigned int h = key_hash(key) & hmask;
         for (int guard = 0; guard < p.hash_cap; ++guard) {
           const int sv = __hip_atomic_load(&tab[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // written by atomics
           if (sv == 0) break;
-          if (nd.key[sv - 1] == key) {
+          const long long k2 = nd.key[sv - 1], st2 = nd.state[sv - 1];
+          const double c2 = nd.cost[sv - 1];
+          if (k2 == key) {
             slot = sv - 1;
+            slot_state = st2;
+            slot_cost = c2;
             break;
           }
           h = (h + 1) & hmask;
@@ -467,12 +473,8 @@ __device__ int plan_search(const d2d_cfg &c, const d2d_state &s, const d2d_plan 
       SP_ADD(5, sp5, sp6);
       const bool is_leader = ok && leader == lane;
       const bool exists = slot >= 0;
-      bool closed = false;
-      double ecost = 0.0;
-      if (ok && exists) {
-        closed = nd.state[slot] == 2;
-        ecost = nd.cost[slot];
-      }
+      const bool closed = exists & (slot_state == 2);
+      const double ecost = slot_cost;
       const unsigned long long newm = __ballot(is_leader && !exists);
       const int nnew = __popcll(newm);
       if (nn + nnew > p.node_cap) {
