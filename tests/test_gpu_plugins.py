@@ -165,6 +165,39 @@ def test_full_size_closed_loop_properties(pkg, hip):
     assert np.array_equal(env.state.drone[0, :3].cpu().numpy(), fx['t_drone'][119])
 
 
+def test_replicas_stay_identical_at_65536_envs(pkg, hip):
+    """65 536 envs (20 GB of plugin scratch: every per-env offset beyond 32 bits): 256 worlds tiled over the batch, 150
+    closed-loop steps with auto reset -- every env must equal the first replica of its world in the env state AND the plugin
+    state, which an index overflow anywhere in the high envs would break."""
+    from drone2d_amd import vec_env, host_init
+    p = pkg.Params(planner='Primitive', gaze_method='Oxford', agent_number=10, agent_radius=15, agent_max_speed=20,
+                   drone_max_speed=40, map_id=1)
+    K, B = 256, 65536
+    worlds = [host_init.init_world(_with_map(p, 1 + i)) for i in range(K)]
+    env = vec_env.VecDrone2DEnv(p, B, backend=hip, planner='Primitive', device_plugins=True, gaze='Oxford',
+                                worlds=[worlds[i % K] for i in range(B)])
+    for _ in range(3):
+        env.closed_loop(50, auto_reset=True)
+    env.sync()
+    for name in ('drone', 'counters', 'dmap', 'gt', 'kf', 'agents', 'active', 'flags', 'action', 'wp'):
+        t = env.state.t[name]
+        t = t.view(B // K, K, *t.shape[1:])
+        assert bool((t == t[:1]).all()), name
+    for name in ('traj_hdr', 'seen_step', 'trk_radius', 'trk_prev', 'plan_stat'):
+        t = env.plugins.t[name]
+        t = t.view(B // K, K, *t.shape[1:])
+        assert bool((t == t[:1]).all()), name
+    assert int(env.plugins.t['plan_stat'][:, 3].sum()) == 0
+    # and the first replicas are what a 256-env batch computes
+    small = vec_env.VecDrone2DEnv(p, K, backend=hip, planner='Primitive', device_plugins=True, gaze='Oxford', worlds=worlds)
+    for _ in range(3):
+        small.closed_loop(50, auto_reset=True)
+    small.sync()
+    for name in ('drone', 'counters', 'dmap', 'kf', 'flags'):
+        assert torch.equal(env.state.t[name][:K], small.state.t[name]), name
+    assert torch.equal(env.plugins.t['traj_hdr'][:K], small.plugins.t['traj_hdr'])
+
+
 def _with_map(p, map_id):
     import copy
     q = copy.copy(p)
