@@ -197,13 +197,21 @@ __device__ unsigned long long d2d_search_prof[16];
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); \
     var = __builtin_amdgcn_s_memtime();                        \
   } while (0)
+// sections accumulate in (scalar) registers and reach memory once per search: a read-modify-write of the global
+// counters per section would put an L2 round trip into every measured interval
 #define SP_ADD(idx, t0, t1) \
   do {                      \
-    if (e == 0 && lane == 0) d2d_search_prof[idx] += (t1) - (t0); \
+    spacc[idx] += (t1) - (t0); \
+  } while (0)
+#define SP_FLUSH()                                                            \
+  do {                                                                        \
+    if (e == 0 && lane == 0)                                                  \
+      for (int spi = 0; spi < 16; ++spi) d2d_search_prof[spi] += spacc[spi]; \
   } while (0)
 #else
 #define SP_T(var) do { } while (0)
 #define SP_ADD(idx, t0, t1) do { } while (0)
+#define SP_FLUSH() do { } while (0)
 #endif
 
 struct SearchLds {
@@ -238,6 +246,9 @@ __device__ int plan_search(const d2d_cfg &c, const d2d_state &s, const d2d_plan 
 
   unsigned long long spa = 0, spb = 0;
   (void)spa; (void)spb;
+#ifdef D2D_SEARCH_PROF
+  unsigned long long spacc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
   SP_T(spa);
   for (int i = lane; i < p.hash_cap; i += WAVE) tab[i] = 0;
   for (int i = lane; i < p.nu; i += WAVE) S.us[i] = p.u_space[i];
@@ -433,27 +444,47 @@ __device__ int plan_search(const d2d_cfg &c, const d2d_state &s, const d2d_plan 
       }
       SP_T(sp5);
       SP_ADD(4, sp4, sp5);
-      // the successors among themselves, through LDS (rank order = lane order = generation order): the first lane
-      // of a key owns its place in the dict, the cheapest (earliest on ties) its value
+      // the successors among themselves (rank order = lane order = generation order): the first lane of a key owns its
+      // place in the dict, the cheapest (earliest on ties) its value.  Repeats within one expansion are rare, so the
+      // common path only ASKS whether any two of the ~10 keys are equal -- one scalar round per successor (readlane of
+      // its key, compare, ballot), no LDS hand-off; the full resolution through LDS runs when the answer is yes.
       const unsigned long long m = __ballot(ok);
       const int nok = __popcll(m), rank = __popcll(m & lt_mask);
-      if (ok) {
-        S.rk[rank] = key;
-        S.rv[rank] = cost;
-        S.ri[rank] = lane;
+      unsigned long long dupm = 0;  // wave-uniform: successors whose key another successor carries too
+      {
+        const int klo = (int)(unsigned int)(unsigned long long)key, khi = (int)(unsigned int)((unsigned long long)key >> 32);
+        unsigned long long mm = m;
+        while (mm != 0ull) {  // four successors per trip: their readlanes and compares are independent chains
+          int j4[4];
+          int jl = 0;
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            jl = mm != 0ull ? (int)__builtin_ctzll(mm) : jl;  // past the last one: repeat it (adds nothing)
+            j4[u] = jl;
+            mm &= mm - 1ull;
+          }
+          unsigned int jlo[4], jhi[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            jlo[u] = (unsigned int)__builtin_amdgcn_readlane(klo, j4[u]);
+            jhi[u] = (unsigned int)__builtin_amdgcn_readlane(khi, j4[u]);
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const long long kj = (long long)(((unsigned long long)jhi[u] << 32) | jlo[u]);
+            dupm |= __ballot(ok & (key == kj)) & ~(1ull << j4[u]);
+          }
+        }
       }
-      wave_sync_lds();
       int leader = lane, wlane = lane;
       double wcost = cost;
-      bool dup = false;
-      for (int j0 = 0; j0 < nok; j0 += 8) {  // keys only, eight at a time: repeats within one expansion are rare
-        long long k8[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) k8[u] = S.rk[min(j0 + u, nok - 1)];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) dup = dup | (ok & (j0 + u < nok) & (j0 + u != rank) & (k8[u] == key));
-      }
-      if (__any(dup)) {  // rare: a plain loop keeps the register pressure of the common path low
+      if (dupm != 0ull) {  // rare: a plain loop keeps the register pressure of the common path low
+        if (ok) {
+          S.rk[rank] = key;
+          S.rv[rank] = cost;
+          S.ri[rank] = lane;
+        }
+        wave_sync_lds();
         leader = lane;
         wlane = -1;
         wcost = 0.0;
@@ -511,11 +542,9 @@ __device__ int plan_search(const d2d_cfg &c, const d2d_state &s, const d2d_plan 
       SP_T(sp8);
       SP_ADD(7, sp7, sp8);
       SP_ADD(8, sp0, sp8);
-      if (e == 0 && lane == 0) {
 #ifdef D2D_SEARCH_PROF
-        d2d_search_prof[9] += 1;
+      spacc[9] += 1;
 #endif
-      }
     }
     if (overflow) break;
   }
@@ -525,7 +554,10 @@ __device__ int plan_search(const d2d_cfg &c, const d2d_state &s, const d2d_plan 
     stat[2] = nn;
     if (overflow) stat[3] = 1;
   }
-  if (goal < 0 || overflow) return -1;
+  if (goal < 0 || overflow) {
+    SP_FLUSH();
+    return -1;
+  }
   SP_T(spa);
   // ---- :207-216: waypoints of every primitive on the path, start side first ----
   int depth = 0;
@@ -561,8 +593,9 @@ __device__ int plan_search(const d2d_cfg &c, const d2d_state &s, const d2d_plan 
   SP_T(spb);
   SP_ADD(11, spa, spb);
 #ifdef D2D_SEARCH_PROF
-  if (e == 0 && lane == 0) d2d_search_prof[12] += 1;
+  spacc[12] += 1;
 #endif
+  SP_FLUSH();
   return total;
 }
 
