@@ -110,6 +110,28 @@ __device__ __forceinline__ double sq_threshold(double L) {
   return t;
 }
 
+// The tracker part of Planner.is_free (traj_planner.py:52-58): is (x, y) at time t within the safety radius of an active
+// tracker's predicted position?  Four trackers per round, loads first: one tracker per iteration pays the LDS latency
+// once per tracker (the trip count is dynamic, the compiler does not pipeline it).  The planes are padded to a multiple
+// of four entries.
+__device__ __forceinline__ bool plan_hits_tracker(const TrkView &T, double x, double y, double t) {
+  bool hit = false;
+  for (int q = 0; q < T.n; q += 4) {
+    double mx[4], my[4], vx[4], vy[4], lim[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      mx[u] = T.mx[q + u]; my[u] = T.my[q + u]; vx[u] = T.vx[q + u]; vy[u] = T.vy[q + u]; lim[u] = T.lim_plan[q + u];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const double ex = mx[u] + t * vx[u], ey = my[u] + t * vy[u];  // estimate_pos, utils.py:220-223
+      const double dx = x - ex, dy = y - ey;
+      hit = hit | ((q + u < T.n) & (__builtin_fma(dy, dy, dx * dx) <= lim[u]));
+    }
+  }
+  return hit;
+}
+
 // Planner.is_free, traj_planner.py:28-59.  The five probes (x -+ d, y), (x, y), (x, y -+ d) of get_grid
 // (utils.py:545-548) share three column and three row indices; loads are unconditional (clamped) and in flight together.
 template <typename DM>
@@ -130,24 +152,31 @@ __device__ __forceinline__ bool plan_is_free(const d2d_cfg &c, const d2d_plan &p
   const bool oy0 = (yl >= c.H_px) | (yl < 0.0), oy1 = (y >= c.H_px) | (y < 0.0), oy2 = (yr >= c.H_px) | (yr < 0.0);
   const bool wall = (ox0 | oy1 | (v0 == D2D_OCCUPIED)) | (ox1 | oy1 | (v1 == D2D_OCCUPIED)) | (ox2 | oy1 | (v2 == D2D_OCCUPIED)) |
                     (ox1 | oy0 | (v3 == D2D_OCCUPIED)) | (ox1 | oy2 | (v4 == D2D_OCCUPIED));
-  // Four trackers per round, loads first: one tracker per iteration pays the LDS latency once per tracker (the trip
-  // count is dynamic, the compiler does not pipeline it).  The planes are padded to a multiple of four entries.
-  bool hit = false;
-  for (int q = 0; q < T.n; q += 4) {
-    double mx[4], my[4], vx[4], vy[4], lim[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      mx[u] = T.mx[q + u]; my[u] = T.my[q + u]; vx[u] = T.vx[q + u]; vy[u] = T.vy[q + u]; lim[u] = T.lim_plan[q + u];
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const double ex = mx[u] + t * vx[u], ey = my[u] + t * vy[u];  // estimate_pos, utils.py:220-223
-      const double dx = x - ex, dy = y - ey;
-      hit = hit | ((q + u < T.n) & (__builtin_fma(dy, dy, dx * dx) <= lim[u]));
-    }
-  }
-  return !wall && !hit;
+  return !wall && !plan_hits_tracker(T, x, y, t);
 }
+
+// The wall part of is_free for the planner's collision samples on the default grid scale: the samples are integer-valued
+// (np.around), the safety distance is an integer, so the five probes are integer arithmetic -- two conversions, then
+// 24-bit multiplies for floor(v / 10) == (v * 52429) >> 19 (exact below 81920) -- instead of six fp64 floor divisions.
+// `xi`, `yi`: the sample, already known to lie within +-2^22; `di`: the safety distance; Wpx / Hpx: the map in pixels.
+template <typename DM>
+__device__ __forceinline__ bool plan_wall_int(const d2d_cfg &c, DM dm, int xi, int yi, int di, int Wpx, int Hpx) {
+  const int xl = xi - di, xr = xi + di, yl = yi - di, yr = yi + di;
+  // out of the map = wall: v < 0 or v >= size, one unsigned compare
+  const bool ox0 = (unsigned int)xl >= (unsigned int)Wpx, ox1 = (unsigned int)xi >= (unsigned int)Wpx, ox2 = (unsigned int)xr >= (unsigned int)Wpx;
+  const bool oy0 = (unsigned int)yl >= (unsigned int)Hpx, oy1 = (unsigned int)yi >= (unsigned int)Hpx, oy2 = (unsigned int)yr >= (unsigned int)Hpx;
+  const int Wm = Wpx - 1, Hm = Hpx - 1;
+#define D2D_BY10(v, m) ((int)(__umul24((unsigned int)min(max((v), 0), (m)), 52429u) >> 19))
+  const int W1 = c.W - 1, H1 = c.H - 1;  // an out-of-range probe is a wall whatever it reads: only its address must be valid
+  const int i0 = min(D2D_BY10(xl, Wm), W1), i1 = min(D2D_BY10(xi, Wm), W1), i2 = min(D2D_BY10(xr, Wm), W1);
+  const int j0 = min(D2D_BY10(yl, Hm), H1), j1 = min(D2D_BY10(yi, Hm), H1), j2 = min(D2D_BY10(yr, Hm), H1);
+#undef D2D_BY10
+  const unsigned char v0 = dm[i0 * c.H + j1], v1 = dm[i1 * c.H + j1], v2 = dm[i2 * c.H + j1], v3 = dm[i1 * c.H + j0],
+                      v4 = dm[i1 * c.H + j2];
+  return (ox0 | oy1 | (v0 == D2D_OCCUPIED)) | (ox1 | oy1 | (v1 == D2D_OCCUPIED)) | (ox2 | oy1 | (v2 == D2D_OCCUPIED)) |
+         (ox1 | oy0 | (v3 == D2D_OCCUPIED)) | (ox1 | oy2 | (v4 == D2D_OCCUPIED));
+}
+
 
 // Primitive_Node.get_index, traj_planner.py:93: (round(x) // 10, round(y) // 10, round(vx), round(vy)); the floor
 // division of the rounded coordinate is exact in fp64 (cell_fast), no 64-bit integer division
@@ -291,6 +320,11 @@ __device__ int plan_search(const d2d_cfg &c, const d2d_state &s, const d2d_plan 
   const int nprim = p.nu * p.nu;
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
   const FastDiv fd_nu(p.nu), fd_ns(p.n_sample);
+  // integer probes for the collision samples (plan_wall_int): grid scale 10, map below 81920 px, integer safety distance
+  const bool int_walls = c.scale == 10.0 && c.W_px <= 81919.0 && c.H_px <= 81919.0 && c.W_px == floor(c.W_px) &&
+                         c.H_px == floor(c.H_px) && c.W_px >= 1.0 && c.H_px >= 1.0 && p.safe_dist >= 0.0 &&
+                         p.safe_dist <= 1048576.0 && p.safe_dist == floor(p.safe_dist);
+  const int safe_i = int_walls ? (int)p.safe_dist : 0, wpx_i = int_walls ? (int)c.W_px : 1, hpx_i = int_walls ? (int)c.H_px : 1;
   for (;;) {
     itr += 1;
     if (open_n == 0 || itr >= p.max_itr) break;
@@ -384,7 +418,8 @@ __device__ int plan_search(const d2d_cfg &c, const d2d_state &s, const d2d_plan 
         // dependent LDS round trips (list -> tables -> map bytes -> counter), clamped indices keep both chains unconditional
         for (int q0 = 0; q0 < npair; q0 += 2 * WAVE) {
           int pr[2], sia[2], sja[2], si[2];
-          bool in[2], fr[2];
+          bool in[2], fr[2], fits[2];
+          double sxv[2], syv[2], tgv[2];
 #pragma unroll
           for (int u = 0; u < 2; ++u) {
             const int q = q0 + u * WAVE + lane;
@@ -406,8 +441,22 @@ __device__ int plan_search(const d2d_cfg &c, const d2d_state &s, const d2d_plan 
             const double shx = ux[u] / 2, shy = uy[u] / 2;
             const double sx = rint(__builtin_fma(tt2[u], shx, px + tt[u] * vx)), sy = rint(__builtin_fma(tt2[u], shy, py + tt[u] * vy));
             const double tg = tt[u] + (double)citr * H;
-            fr[u] = lds_map ? plan_is_free(c, p, (const unsigned char *)S.map, T, sx, sy, tg, inv_scale)
-                            : plan_is_free(c, p, dm, T, sx, sy, tg, inv_scale);
+            sxv[u] = sx; syv[u] = sy; tgv[u] = tg;
+            fits[u] = (fabs(sx) <= 4194304.0) & (fabs(sy) <= 4194304.0);  // also false for NaN
+          }
+          if (int_walls && __all((int)fits[0] & (int)fits[1])) {  // wave-uniform: integer probes, see plan_wall_int
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+              const int xi = (int)sxv[u], yi = (int)syv[u];
+              const bool wall = lds_map ? plan_wall_int(c, (const unsigned char *)S.map, xi, yi, safe_i, wpx_i, hpx_i)
+                                        : plan_wall_int(c, dm, xi, yi, safe_i, wpx_i, hpx_i);
+              fr[u] = !wall && !plan_hits_tracker(T, sxv[u], syv[u], tgv[u]);
+            }
+          } else {
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+              fr[u] = lds_map ? plan_is_free(c, p, (const unsigned char *)S.map, T, sxv[u], syv[u], tgv[u], inv_scale)
+                              : plan_is_free(c, p, dm, T, sxv[u], syv[u], tgv[u], inv_scale);
           }
 #pragma unroll
           for (int u = 0; u < 2; ++u)
