@@ -60,33 +60,25 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
 }
 
-// Lexicographic (cost, slot) minimum over the wave, returned wave-uniform: four DPP steps fold every row of 16 lanes
-// into its last lane, four readlanes fold the rows.  (+inf, INT_MAX) is "no candidate".
+// Lexicographic (cost, slot) minimum over the wave, returned wave-uniform, in two plain reductions: the minimum cost
+// (never NaN: a lane's candidate starts at +inf and is only replaced through `<`), then the smallest slot among the lanes
+// that hold it.  Four DPP steps fold every row of 16 lanes into its last lane, readlanes fold the rows.
+// (+inf, INT_MAX) is "no candidate".
 __device__ __forceinline__ int wave_argmin(double t, int idx) {
-#define D2D_ARGMIN_STEP(N)                                             \
-  {                                                                    \
-    const double t2 = row_shr_f64<N>(t);                               \
-    const int i2 = row_shr_i32<N>(idx);                                \
-    const bool take = (t2 < t) | ((t2 == t) & (i2 < idx));             \
-    t = take ? t2 : t;                                                 \
-    idx = take ? i2 : idx;                                             \
-  }
-  D2D_ARGMIN_STEP(1)
-  D2D_ARGMIN_STEP(2)
-  D2D_ARGMIN_STEP(4)
-  D2D_ARGMIN_STEP(8)
-#undef D2D_ARGMIN_STEP
-  double b = readlane_f64(t, 15);
-  int bi = __builtin_amdgcn_readlane(idx, 15);
-#pragma unroll
-  for (int row = 1; row < 4; ++row) {
-    const double t2 = readlane_f64(t, 16 * row + 15);
-    const int i2 = __builtin_amdgcn_readlane(idx, 16 * row + 15);
-    const bool take = (t2 < b) | ((t2 == b) & (i2 < bi));
-    b = take ? t2 : b;
-    bi = take ? i2 : bi;
-  }
-  return bi;
+  double m = t;
+  m = __builtin_fmin(m, row_shr_f64<1>(m));
+  m = __builtin_fmin(m, row_shr_f64<2>(m));
+  m = __builtin_fmin(m, row_shr_f64<4>(m));
+  m = __builtin_fmin(m, row_shr_f64<8>(m));
+  const double wmin = __builtin_fmin(__builtin_fmin(readlane_f64(m, 15), readlane_f64(m, 31)),
+                                     __builtin_fmin(readlane_f64(m, 47), readlane_f64(m, 63)));
+  int c = (t == wmin) ? idx : 0x7fffffff;
+  c = min(c, row_shr_i32<1>(c));
+  c = min(c, row_shr_i32<2>(c));
+  c = min(c, row_shr_i32<4>(c));
+  c = min(c, row_shr_i32<8>(c));
+  return min(min(__builtin_amdgcn_readlane(c, 15), __builtin_amdgcn_readlane(c, 31)),
+             min(__builtin_amdgcn_readlane(c, 47), __builtin_amdgcn_readlane(c, 63)));
 }
 
 struct TrkView {  // active trackers of the env, compacted into LDS
