@@ -491,31 +491,26 @@ __device__ int plan_search(const d2d_cfg &c, const d2d_state &s, const d2d_plan 
       // its key, compare, ballot), no LDS hand-off; the full resolution through LDS runs when the answer is yes.
       const unsigned long long m = __ballot(ok);
       const int nok = __popcll(m), rank = __popcll(m & lt_mask);
-      unsigned long long dupm = 0;  // wave-uniform: successors whose key another successor carries too
+      // every successor puts its key into a 64-bucket LDS table (the path buffer, free at this point) by compare-and-swap:
+      // finding its own key there = a repeat; another key = next bucket.  One or two LDS round trips for ten keys, and exact:
+      // the resolution below runs only when two successors really share a key (or a key equals the empty marker, 0)
+      unsigned long long dupm = 0;
       {
-        const int klo = (int)(unsigned int)(unsigned long long)key, khi = (int)(unsigned int)((unsigned long long)key >> 32);
-        unsigned long long mm = m;
-        while (mm != 0ull) {  // four successors per trip: their readlanes and compares are independent chains
-          int j4[4];
-          int jl = 0;
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            jl = mm != 0ull ? (int)__builtin_ctzll(mm) : jl;  // past the last one: repeat it (adds nothing)
-            j4[u] = jl;
-            mm &= mm - 1ull;
-          }
-          unsigned int jlo[4], jhi[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            jlo[u] = (unsigned int)__builtin_amdgcn_readlane(klo, j4[u]);
-            jhi[u] = (unsigned int)__builtin_amdgcn_readlane(khi, j4[u]);
-          }
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const long long kj = (long long)(((unsigned long long)jhi[u] << 32) | jlo[u]);
-            dupm |= __ballot(ok & (key == kj)) & ~(1ull << j4[u]);
-          }
+        unsigned long long *bk = (unsigned long long *)chain;
+        bk[lane] = 0ull;  // LDS operations of one wave execute in order: the swaps below see the cleared table
+        const unsigned long long ukey = (unsigned long long)key;
+        unsigned int hb = ((unsigned int)ukey + (unsigned int)(ukey >> 32) * 0x9E3779B1u) >> 26;
+        const bool odd = ok & (ukey == 0ull);
+        bool rep = false, pending = ok & !odd;
+        for (int trip = 0; trip < WAVE && __any(pending); ++trip) {  // <= 64 keys in 64 buckets: always terminates
+          unsigned long long old = 0ull;
+          if (pending) old = atomicCAS(&bk[hb], 0ull, ukey);
+          const bool same = pending & (old == ukey);
+          rep = rep | same;
+          pending = pending & (old != 0ull) & !same;
+          hb = (hb + 1u) & 63u;
         }
+        dupm = __ballot(rep | odd);
       }
       int leader = lane, wlane = lane;
       double wcost = cost;
