@@ -434,7 +434,7 @@ __device__ int plan_search(const d2d_cfg &c, const d2d_state &s, const d2d_plan 
             const double sx = rint(__builtin_fma(tt2[u], shx, px + tt[u] * vx)), sy = rint(__builtin_fma(tt2[u], shy, py + tt[u] * vy));
             const double tg = tt[u] + (double)citr * H;
             sxv[u] = sx; syv[u] = sy; tgv[u] = tg;
-            fits[u] = (fabs(sx) <= 4194304.0) & (fabs(sy) <= 4194304.0);  // also false for NaN
+            fits[u] = fabs(sx) <= 4194304.0 && fabs(sy) <= 4194304.0;  // also false for NaN
           }
           if (int_walls && __all((int)fits[0] & (int)fits[1])) {  // wave-uniform: integer probes, see plan_wall_int
 #pragma unroll
