@@ -720,7 +720,8 @@ __device__ __forceinline__ bool plan_env_quick(const d2d_cfg &c, const d2d_state
     if (act) {
       const int q = nact + __popcll(am & ((1ull << lane) - 1ull));
       T.mx[q] = m0; T.my[q] = m1; T.vx[q] = m2; T.vy[q] = m3;
-      T.lim_plan[q] = sq_threshold(c.drone_radius + rad + 5 + c.sigma);  // traj_planner.py:58
+      T.lim_plan[q] = c.drone_radius + rad + 5 + c.sigma;  // traj_planner.py:58: the limit itself; only a search needs its
+                                                           // squared threshold (plan_env_search), a few percent of the steps
       T.lim_replan[q] = sq_threshold(c.drone_radius + rad);              // traj_planner.py:228
     }
     nact += __popcll(am);
@@ -781,6 +782,8 @@ __device__ __forceinline__ void plan_env_search(const d2d_cfg &c, const d2d_stat
   SearchLds S;
   plan_carve(c, p, base, T, S);
   T.n = S.misc[0];  // the trackers are still in LDS
+  for (int q = lane; q < T.n; q += WAVE) T.lim_plan[q] = sq_threshold(T.lim_plan[q]);
+  wave_sync_lds();
   const double inv_scale = 1.0 / c.scale;
   const unsigned char *__restrict__ dm = s.dmap + (size_t)e * c.W * c.H;
   // A search is a long chain of short dependent steps and, in the persistent loop, what the slowest env of a launch
