@@ -56,7 +56,11 @@ N_SEEDS = int(os.environ.get('D2D_RANDOM_SEEDS', '48'))      # a soak run sets t
 SEED_BASE = int(os.environ.get('D2D_RANDOM_BASE', '0'))      # ... and moves on to fresh configurations
 
 
-@pytest.mark.parametrize('seed', range(SEED_BASE, SEED_BASE + N_SEEDS))
+# seeds that exposed defects in earlier soaks stay in the default run (1892, 2563: a search whose start node is the goal)
+REGRESSION_SEEDS = [1892, 2563, 20003, 30011, 40002, 50001]
+
+
+@pytest.mark.parametrize('seed', list(range(SEED_BASE, SEED_BASE + N_SEEDS)) + (REGRESSION_SEEDS if SEED_BASE == 0 else []))
 def test_random_closed_loop_matches_oracle(pkg, hip, oracle, seed):
     rng = np.random.RandomState(1000 + seed)
     kw = _random_cfg(rng)

@@ -44,7 +44,11 @@ def _cfg(rng):
     return kw
 
 
-@pytest.mark.parametrize('seed', range(SEED_BASE, SEED_BASE + N_SEEDS))
+# seeds that exposed the narrow-crop-tile defect (view depth below 80 px) stay in the default run
+REGRESSION_SEEDS = [106, 121, 289, 290, 541, 611]
+
+
+@pytest.mark.parametrize('seed', list(range(SEED_BASE, SEED_BASE + N_SEEDS)) + (REGRESSION_SEEDS if SEED_BASE == 0 else []))
 def test_random_step_matches_oracle(pkg, hip, oracle, seed):
     rng = np.random.RandomState(7000 + seed)
     kw = _cfg(rng)
