@@ -5,23 +5,36 @@
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W
 
-Workload (N=1): BASELINE.json configs[1] — 4096 batched envs x 10 agents, agent_radius=15, 50x50 grid, 50 rays,
-Oxford gaze, Primitive planner; env i = the reference world for map_id 1+i.  A "step" = one reference-style step
-of every env: a = Oxford.plan(info); Drone2DEnv2.step(a) with Primitive.replan_check / plan in the middle
+Workload (default, N=1): BASELINE.json configs[1] — 4096 batched envs x 10 agents, agent_radius=15, 50x50 grid, 50
+rays, Oxford gaze, Primitive planner; env i = the reference world for map_id 1+i.  A "step" = one reference-style
+step of every env: a = Oxford.plan(info); Drone2DEnv2.step(a) with Primitive.replan_check / plan in the middle
 (experiment.py:68-70), ALL of it on the device (d2d_closed_loop: one persistent launch, every wave loops over the
-steps of its own env), finished episodes restarting from their seeded world (main.py:26-57).  Nothing is replayed
-or skipped inside the timed region.  State is resident in HBM before the timed region.
+steps of its own env), finished episodes restarting from their seeded world (main.py:26-57).  Nothing is replayed or
+skipped inside the timed region.  State is resident in HBM before the timed region.
 
-Besides the headline the line carries `step_kernel`: the fused Drone2DEnv2.step kernel alone (k_stages; gaze
-actions and planner heads resident in HBM, SURVEY.md 8(d) C2's replay mode), timed with HIP events after the
-timed region -- the HBM-roofline figure of the raycast / step kernel the north star asks for.
+Steady state whatever --steps / --warmup say: an untimed PROLOGUE (--prologue, 300 steps) runs before the warm-up, so
+that the timed window holds episode ends, restarts and the steady search rate even when it is 20 steps long; the
+line reports `searches_per_env_per_step` and `episode_ends` OF THE TIMED WINDOW.
 
-N>1: every rank runs its own shard of 4096 envs (weak scaling, no per-step collective; one RCCL all_gather of
-episode statistics).  Prints ONE JSON line on rank 0.
+Other BASELINE configurations: --workload config3 | config4 | config5 (envs per GPU: 65536 / 32768 / 32768, override
+with --envs).  config5 (640 x 640 cells, 640 rays, 100 agents) names no plugins and its maps are beyond the plugin
+stages' LDS working sets: its step is the fused Drone2DEnv2.step alone (NoMove), fixed-seed gaze actions.
+
+Besides the headline the line carries, measured after the timed region with HIP events on the launch stream:
+  step_kernel    the fused Drone2DEnv2.step kernel alone (k_stages; actions and planner heads resident in HBM)
+  raycast_stage  d2d_run_stages(AGENTS | RAYCAST): the raycast kernel the north star's HBM target is quoted on
+(--leg picks one of them for a profiler run: every k_stages row of that trace is then that leg).
+PMC-derived fields (`traffic`, `valu`) come from profiles/pmc_latest.json, which stores them PER ENV-STEP together
+with the launch shape they were measured on; they are scaled to this run's launch and emitted only when workload,
+envs and launch mode match the profile (else null), with `traffic_source` naming the file.
+
+N>1: every rank runs its own shard (weak scaling, no per-step collective; one RCCL all_gather of episode statistics,
+timed separately as `gather_ms`).  Prints ONE JSON line on rank 0.
 """
 import argparse
 import ctypes as C
 import json
+import math
 import os
 import sys
 import time
@@ -29,10 +42,39 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-ALGO_BYTES_PER_ENV_STEP = 3844      # N=10, c=9, R=50, S=10, L=33
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E 8 TB/s
 N_SIMD = 256 * 4                    # 256 CUs x 4 SIMDs
 CLOCK_HZ = 2.4e9                    # nominal shader clock (the chip runs at or below it under load)
+PMC_FILE = os.path.join('profiles', 'pmc_latest.json')
+
+WORKLOADS = {
+    # name: (envs per GPU, Params overrides, closed loop?, description)
+    'config2': (4096, dict(agent_number=10, agent_radius=15, agent_max_speed=20), True,
+                'configs[1]: {B} batched envs per GPU x 10 agents, agent_radius=15, 50x50 uint8 grid, 50 rays, map_id=1+env, '
+                'Oxford gaze + Primitive planner'),
+    'config3': (65536, dict(agent_number=50, agent_radius=10, agent_max_speed=40, static_map='maps/random_map_0.npy'), True,
+                'configs[2]: {B} envs per GPU x 50 agents at max_speed=40 + 122 random_map_0 agents, Oxford + Primitive'),
+    'config4': (32768, dict(agent_number=10, agent_radius=15, agent_max_speed=20, static_map='maps/obstacle_map.npy'), True,
+                'configs[3]: {B} envs per GPU (262144 over 8) x 10 agents + 14 obstacle_map agents, Oxford + Primitive'),
+    'config5': (32768, dict(agent_number=100, agent_radius=15, agent_max_speed=40, map_size=[6400, 6400], init_pos=[3200, 3200],
+                            target_list=[[6000, 6000]]), False,
+                'configs[4]: {B} envs per GPU (262144 over 8) x 100 agents, 640x640 uint8 grid, 640 rays; fused '
+                'Drone2DEnv2.step (NoMove), fixed-seed gaze actions'),
+}
+
+
+def algo_bytes(cfg, agent_unit, stages='step'):
+    """SURVEY.md 8(d), from the ACTUAL configuration: 36 N (agents) + 3 c N (dynamic grid, c = (2 u + 1)^2 cells per agent)
+    + N (hit mask) + R S + R (S - 1) (ground-truth reads + drone-map writes, S samples per ray) + 2 L^2 (observation crop)
+    + 76 (drone state, action, plan in; state, flags out).  `stages` = 'raycast': the AGENTS | RAYCAST launch alone
+    (agents, hit mask, ray cells, 44 B of drone state in)."""
+    N, R, L = cfg.N, cfg.R, cfg.L
+    S = int(math.ceil(cfg.depth / (cfg.scale - 1.0))) + 1
+    rays = R * S + R * (S - 1)
+    if stages == 'raycast':
+        return 36 * N + N + rays + 44
+    cells = float(((2 * agent_unit.double() + 1) ** 2).sum(1).mean()) if N else 0.0
+    return 36 * N + 3 * cells + N + rays + 2 * L * L + 76
 
 
 def synth_plan(torch, T, B, W_px, H_px, seed, device):
@@ -65,102 +107,154 @@ def host_cores():
     return n
 
 
-def cpu_baseline(pkg, params, budget_s=16.0):
+def cpu_baseline(pkg, params, closed, budget_s=16.0):
     """The CPU oracle (oracle/, a scalar C port of the reference: step + Oxford + Primitive) timed on this box's
-    host cores on a bounded sample of the same workload: the same closed loop (gaze -> perceive -> plan -> act,
-    auto reset) over 512 envs of the same family.  Timed on 1 thread and on min(cores, 32) OpenMP threads over
-    envs; the faster is reported with the thread count actually used."""
+    host cores on a bounded sample of the same workload: the same loop over 512 envs (64 for the 640 x 640 maps) of the
+    same family.  Timed on 1 thread and on min(cores, 32) OpenMP threads over envs; the faster is reported with the
+    thread count actually used."""
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     from oracle_lib import OracleBackend
     from drone2d_amd import vec_env
     ob = OracleBackend()
     avail = host_cores()
     many = max(1, min(avail, 32))
-    B = 512
-    worlds = vec_env.build_worlds(params, 64, workers=0)
+    big_map = params.map_size[0] * params.map_size[1] > 1000 * 1000
+    B, nw = (64, 16) if big_map else (512, 64)
+    worlds = vec_env.build_worlds(params, nw, workers=0)
     out = {}
     for threads in sorted({1, many}):
-        env = vec_env.VecDrone2DEnv(params, B, backend=ob, planner='Primitive', device_plugins=True, gaze='Oxford',
-                                    worlds=[worlds[i % 64] for i in range(B)])
+        if closed:
+            env = vec_env.VecDrone2DEnv(params, B, backend=ob, planner='Primitive', device_plugins=True, gaze='Oxford',
+                                        worlds=[worlds[i % nw] for i in range(B)])
+        else:
+            env = vec_env.VecDrone2DEnv(params, B, backend=ob, planner='NoMove', worlds=[worlds[i % nw] for i in range(B)])
         ob.lib.d2d_oracle_set_threads(threads)
         n = 0
         t0 = time.perf_counter()
         while time.perf_counter() - t0 < budget_s / 2:
-            env.closed_loop(2, auto_reset=True)
+            if closed:
+                env.closed_loop(2, auto_reset=True)
+            else:
+                env.step(0.25)
+                env.step(-0.5)
             n += 2
         out[threads] = B * n / (time.perf_counter() - t0)
     ob.lib.d2d_oracle_set_threads(1)
     best = max(out, key=out.get)
+    loop = 'closed loop (Oxford + Primitive + step, auto reset)' if closed else 'fused step (NoMove)'
     return {'value': out[best], 'unit': 'env-steps/s', 'cores': best, 'kind': 'port',
             'single_core_value': out[1], 'host_cores_available': avail,
-            'sample': f'oracle/d2d_oracle.c closed loop (Oxford + Primitive + step, auto reset), {B} envs x 10 agents (64 '
-                      f'distinct seeded worlds of the GPU workload\'s family), ~{budget_s / 2:.0f} s per thread count '
-                      f'{sorted(out)}; reference Python itself: 16.3 env-steps/s for this loop on 1 core (BASELINE.md, '
-                      'build container)'}
+            'sample': f'oracle/d2d_oracle.c {loop}, {B} envs x {env.N} agents ({nw} distinct seeded worlds of the GPU '
+                      f'workload\'s family), ~{budget_s / 2:.0f} s per thread count {sorted(out)}; reference Python itself: '
+                      '16.3 env-steps/s for the config-2 closed loop on 1 core (BASELINE.md, build container)'}
 
 
-def step_kernel_leg(torch, env, params, rank, device, B, K=500, Wm=200):
-    """The fused Drone2DEnv2.step kernel alone: K d2d_step launches over the batch (one launch = B envs), gaze
-    actions and planner heads resident in HBM, timed with HIP events on the launch stream."""
-    T = K + Wm
-    g = torch.Generator().manual_seed(1234 + rank)
-    actions = (torch.rand(T, B, generator=g, dtype=torch.float64) * 2 - 1).to(device)
-    wp = synth_plan(torch, T, B, params.map_size[0], params.map_size[1], 99 + rank, device)
-    env.state.plan_ok.fill_(1)
-    env.state.wp_valid.fill_(1)
-    be = env.backend
-    st = env.state.struct()
-    stream = torch.cuda.current_stream(device)
-    sp = C.c_void_p(stream.cuda_stream)
+class Clock:
+    """HIP events on the launch stream (CPU dry runs of the multi-rank path: wall clock)."""
 
-    def roll(t0, n):
-        rc = be.fn['rollout'](C.byref(env.cfg), C.byref(st), n, actions.data_ptr() + t0 * B * 8, wp.data_ptr() + t0 * B * 48,
-                              None, None, sp)
-        if rc:
-            raise RuntimeError(be.fn['last_error']().decode())
-    roll(0, Wm)
-    torch.cuda.synchronize()
-    reps = []
-    for _ in range(3):       # best of three repetitions of the same K launches (clock transients after the long kernel)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(stream)
-        roll(Wm, K)
-        e1.record(stream)
-        torch.cuda.synchronize()
-        reps.append(e0.elapsed_time(e1) * 1e3 / K)
-    launch_us = min(reps)
-    achieved = ALGO_BYTES_PER_ENV_STEP * B / (launch_us * 1e-6) / 1e9
-    return {'kernel': 'k_stages (fused Drone2DEnv2.step: agents, raycast, dynamic grid, trackers, control, collision, obs)',
-            'inputs': 'fixed-seed U(-1,1) gaze actions and synthetic waypoint heads resident in HBM (replay mode)',
-            'launches': K, 'repetitions_us': reps, 'envs_per_launch': B, 'launch_us': launch_us, 'env_steps_per_s': B / (launch_us * 1e-6),
-            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': _pmc('step_kernel_hbm_bytes_per_launch'),
-                         'algo_bytes_per_env_step': ALGO_BYTES_PER_ENV_STEP},
-            'valu': _valu('k_stages', B / (launch_us * 1e-6))}
+    def __init__(self, torch, device):
+        self.torch, self.device = torch, torch.device(device)
+        self.gpu = self.device.type == 'cuda'
+        self.stream = torch.cuda.current_stream(self.device) if self.gpu else None
+
+    def sync(self):
+        if self.gpu:
+            self.torch.cuda.synchronize(self.device)
+
+    def timed_us(self, fn):
+        if self.gpu:
+            e0, e1 = self.torch.cuda.Event(enable_timing=True), self.torch.cuda.Event(enable_timing=True)
+            e0.record(self.stream)
+            fn()
+            e1.record(self.stream)
+            self.sync()
+            return e0.elapsed_time(e1) * 1e3
+        t0 = time.perf_counter()
+        fn()
+        return (time.perf_counter() - t0) * 1e6
+
+    def stream_ptr(self):
+        return C.c_void_p(self.stream.cuda_stream) if self.gpu else None
 
 
-def _valu(kernel, env_steps_per_s_per_gpu):
-    """VALU-issue view of a kernel ("report both the HBM fraction and VALU utilisation"): the vector-pipe cycles
-    one env-step holds a SIMD (rocprofv3 --pmc SQ_ACTIVE_INST_VALU, committed in profiles/pmc_latest.json) against
-    1024 SIMDs x 2.4 GHz, with the rate measured live in this run."""
-    k = _pmc(kernel) or {}
-    busy = k.get('valu_busy_cycles_per_env_step')
+def _pmc_entry(kernel, shape):
+    """The per-env-step PMC record of `kernel` if it was measured on this launch shape, else None."""
+    try:
+        d = json.load(open(os.path.join(ROOT, PMC_FILE)))
+    except Exception:
+        return None
+    k = d.get(kernel)
+    if not k:
+        return None
+    ks = k.get('shape', {})
+    return k if all(ks.get(n) == v for n, v in shape.items()) else None
+
+
+def roofline(kernel, shape, bytes_per_env_step, envs, steps_per_launch, launch_us, extra=None):
+    achieved = bytes_per_env_step * envs * steps_per_launch / (launch_us * 1e-6) / 1e9
+    k = _pmc_entry(kernel, shape)
+    traffic = k['hbm_bytes_per_env_step'] * envs * steps_per_launch if k and k.get('hbm_bytes_per_env_step') else None
+    r = {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
+         'traffic': traffic,
+         'traffic_source': (f'{PMC_FILE} [{kernel}]: {k["hbm_bytes_per_env_step"]:.0f} B per env-step (rocprofv3 --pmc FETCH_SIZE / '
+                            f'WRITE_SIZE on this launch shape, {k.get("source", "")}) x {envs} envs x {steps_per_launch:g} steps')
+                           if traffic else f'{PMC_FILE} holds no PMC pass for this launch shape {shape}',
+         'launch_us': launch_us, 'envs_per_launch': envs, 'steps_per_launch': steps_per_launch,
+         'algo_bytes_per_env_step': bytes_per_env_step}
+    if extra:
+        r.update(extra)
+    return r
+
+
+def valu(kernel, shape, env_steps_per_s_per_gpu):
+    """VALU-issue view ("report both the HBM fraction and VALU utilisation"): the vector-pipe cycles one
+    env-step holds a SIMD (rocprofv3 --pmc SQ_ACTIVE_INST_VALU, per env-step in profiles/pmc_latest.json, same launch shape)
+    against 1024 SIMDs x 2.4 GHz, with the rate measured live in this run."""
+    k = _pmc_entry(kernel, shape)
+    busy = k.get('valu_busy_cycles_per_env_step') if k else None
     if not busy:
         return None
     ceiling = N_SIMD * CLOCK_HZ / busy
     return {'insts_per_env_step': k.get('valu_insts_per_env_step'), 'salu_insts_per_env_step': k.get('salu_insts_per_env_step'),
             'busy_cycles_per_env_step': busy, 'ceiling_env_steps_per_s': ceiling, 'frac': env_steps_per_s_per_gpu / ceiling,
+            'source': f'{PMC_FILE} [{kernel}]',
             'note': 'issue ceiling of this instruction stream = 1024 SIMDs x 2.4 GHz / vector-pipe cycles per env-step (PMC: per-wave '
-                    'issue cycles, ~4 per instruction; fp64 needs all 4, two waves\' int / f32 instructions can overlap on the SIMD-32, '
-                    'so the true ceiling lies between this figure and twice it)'}
+                    'issue cycles; fp64 needs 4 per instruction, two waves\' int / f32 instructions can overlap on the SIMD-32, so the '
+                    'true ceiling lies between this figure and twice it)'}
 
 
-def _pmc(key):
-    pj = os.path.join(ROOT, 'profiles', 'pmc_latest.json')
-    try:
-        return json.load(open(pj)).get(key)
-    except Exception:
-        return None
+def stage_leg(torch, clock, env, params, rank, B, stages, K=500, Wm=100):
+    """K launches of one k_stages stage set over the batch, actions and planner heads resident in HBM."""
+    A = env.backend.fn
+    T = K + Wm
+    device = env.device
+    g = torch.Generator().manual_seed(1234 + rank)
+    actions = (torch.rand(T, B, generator=g, dtype=torch.float64) * 2 - 1).to(device)
+    sp = clock.stream_ptr()
+    if stages == 'step':
+        wp = synth_plan(torch, T, B, params.map_size[0], params.map_size[1], 99 + rank, device)
+        env.state.plan_ok.fill_(1)
+        env.state.wp_valid.fill_(1)
+        st = env.state.struct()
+
+        def roll(t0, n):
+            rc = A['rollout'](C.byref(env.cfg), C.byref(st), n, actions.data_ptr() + t0 * B * 8,
+                              wp.data_ptr() + t0 * B * 48 if env.cfg.planner_mode == 0 else None, None, None, sp)
+            if rc:
+                raise RuntimeError(A['last_error']().decode())
+    else:
+        st = env.state.struct()
+        bits = 2 | 4                                                  # D2D_ST_AGENTS | D2D_ST_RAYCAST (include/d2d.h)
+
+        def roll(t0, n):
+            for _ in range(n):
+                rc = A['run_stages'](C.byref(env.cfg), C.byref(st), bits, sp)
+                if rc:
+                    raise RuntimeError(A['last_error']().decode())
+    roll(0, Wm)
+    clock.sync()
+    reps = [clock.timed_us(lambda: roll(Wm, K)) / K for _ in range(3)]   # best of three (clock transients after a long kernel)
+    return min(reps), reps
 
 
 def main():
@@ -168,13 +262,13 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=600)
     ap.add_argument('--warmup', type=int, default=300)
-    ap.add_argument('--envs', type=int, default=4096, help='envs per GPU')
-    ap.add_argument('--agents', type=int, default=10)
-    ap.add_argument('--static-map', default='maps/empty_map.npy', help='exploration only: other BASELINE configs')
-    ap.add_argument('--agent-speed', type=int, default=20)
-    ap.add_argument('--agent-radius', type=int, default=15)
+    ap.add_argument('--prologue', type=int, default=300,
+                    help='untimed steps before the warm-up: the timed window then sees steady-state episodes whatever --warmup is')
+    ap.add_argument('--workload', default='config2', choices=sorted(WORKLOADS))
+    ap.add_argument('--envs', type=int, default=0, help='envs per GPU (default: the workload\'s)')
+    ap.add_argument('--leg', default='all', choices=['all', 'closed', 'step', 'raycast'],
+                    help='closed: only the timed region; step / raycast: only that k_stages leg (profiler runs)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-step-kernel', action='store_true', help='skip the step-kernel-only leg after the timed region')
     ap.add_argument('--workers', type=int, default=min(8, os.cpu_count() or 1),
                     help='host processes building the worlds (forked BEFORE the GPU is touched; 0 = in-process, '
                          'use 0 under rocprofv3)')
@@ -184,6 +278,8 @@ def main():
     ap.add_argument('--chunk', type=int, default=300, help='steps per persistent d2d_closed_loop launch')
     ap.add_argument('--no-persistent', action='store_true',
                     help='exploration: one launch per stage per step (gaze, perceive, plan, act) instead of the persistent kernel')
+    ap.add_argument('--distinct-worlds', type=int, default=0,
+                    help='build only this many seeded worlds per rank and tile them over the batch (0 = one world per env)')
     args = ap.parse_args()
 
     import torch
@@ -193,99 +289,163 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    B, K, Wm = args.envs, args.steps, args.warmup
-    params = pkg.Params(planner='Primitive', gaze_method='Oxford', agent_number=args.agents, agent_radius=args.agent_radius,
-                        agent_max_speed=args.agent_speed, drone_max_speed=40, map_id=1, static_map=args.static_map)
+    B0, pkw, closed, descr = WORKLOADS[args.workload]
+    B, K, Wm = (args.envs or B0), args.steps, args.warmup
+    params = pkg.Params(planner='Primitive' if closed else 'NoMove', gaze_method='Oxford' if closed else 'NoControl',
+                        drone_max_speed=40, map_id=1, **pkw)
     # host world construction (the reference's __init__, seeded per global env id) before any GPU call
-    worlds = vec_env.build_worlds(params, B, env_offset=rank * B, workers=args.workers)
+    nw = min(B, args.distinct_worlds) if args.distinct_worlds else B
+    worlds = vec_env.build_worlds(params, nw, env_offset=rank * B, workers=args.workers)
+    if nw < B:
+        worlds = [worlds[i % nw] for i in range(B)]
     if args.single_device:
         local = 0
+    use_cuda = torch.cuda.is_available()
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        torch.cuda.set_device(local)
+        if use_cuda:
+            torch.cuda.set_device(local)
         if args.dist_backend == 'nccl':     # 'nccl' IS RCCL on ROCm: collectives over xGMI
             dist.init_process_group('nccl', device_id=torch.device(f'cuda:{local}'))
         else:
             dist.init_process_group('gloo')
     device = f'cuda:{local}'
-    torch.cuda.set_device(local)
+    if use_cuda:
+        torch.cuda.set_device(local)
+
+    if closed:
+        env = vec_env.VecDrone2DEnv(params, B, device=device, planner='Primitive', env_offset=rank * B, worlds=worlds,
+                                    device_plugins=True, gaze='Oxford')
+        if args.no_persistent:
+            env._plan.launch_args = None
+    else:
+        env = vec_env.VecDrone2DEnv(params, B, device=device, planner='NoMove', env_offset=rank * B, worlds=worlds)
+    device = env.device                     # a CPU backend injected by a dry-run harness reports 'cpu'
     coll_dev = device if args.dist_backend == 'nccl' else 'cpu'
+    clock = Clock(torch, device)
+    algo = algo_bytes(env.cfg, env.state.agent_unit)
+    shape = {'workload': args.workload, 'envs': B, 'persistent': bool(closed and not args.no_persistent)}
+    nlaunch_of = lambda n: (n + args.chunk - 1) // args.chunk if closed else n
 
-    env = vec_env.VecDrone2DEnv(params, B, device=device, planner='Primitive', env_offset=rank * B, worlds=worlds,
-                                device_plugins=True, gaze='Oxford')
-    if args.no_persistent:
-        env._plan.launch_args = None
-    stream = torch.cuda.current_stream(device)
+    if closed:
+        def run(n):
+            for c0 in range(0, n, args.chunk):
+                env.closed_loop(min(args.chunk, n - c0), auto_reset=True)
+    else:
+        g = torch.Generator().manual_seed(4321 + rank)
+        T = args.prologue + Wm + K
+        acts = (torch.rand(min(T, 512), B, generator=g, dtype=torch.float64) * 2 - 1).to(device)
+        cursor = [0]
 
-    def run(n):
-        for c0 in range(0, n, args.chunk):
-            env.closed_loop(min(args.chunk, n - c0), auto_reset=True)
+        def run(n):                         # d2d_rollout: n fused steps queued by one call; finished envs restart per chunk
+            done = 0
+            while done < n:
+                m = min(n - done, acts.shape[0] - cursor[0] % acts.shape[0], args.chunk)
+                env.backend.rollout(env.cfg, env._st, m, acts[cursor[0] % acts.shape[0]:], None, None)
+                env.reset(env.state.flags[:, pkg._abi.F_DONE])
+                cursor[0] += m
+                done += m
 
-    run(Wm)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    e0.record(stream)
-    run(K)
-    e1.record(stream)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    gpu_ms = e0.elapsed_time(e1)                  # HIP-event time of the K steps on the launch stream
-    nlaunch = (K + args.chunk - 1) // args.chunk
+    line = None
+    if args.leg in ('all', 'closed'):
+        run(args.prologue)
+        run(Wm)
+        clock.sync()
+        pstat0 = env.plugins.t['plan_stat'][:, 0].clone() if closed else None
+        stats0 = env.episode_stats()
+        if world > 1:
+            dist.barrier()
+        clock.sync()
+        t0 = time.perf_counter()
+        gpu_us = clock.timed_us(lambda: run(K))   # HIP events around the K steps on the launch stream; syncs
+        if world > 1:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        nlaunch = nlaunch_of(K)
 
-    # episode statistics: the only exchange of the path (RCCL all_gather over xGMI), once per run
-    stats = env.episode_stats()
-    pstat = env.plugins.t['plan_stat'].long()
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-        stats = stats.to(coll_dev)
-        allstats = [torch.empty_like(stats) for _ in range(world)]
-        dist.all_gather(allstats, stats)
-        stats = torch.cat(allstats)
+        # episode statistics: the only exchange of the path (RCCL all_gather over xGMI), once per run
+        stats = env.episode_stats()
+        gather_ms, ranks_seen = None, 1
+        if world > 1:
+            tmax = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            elapsed = float(tmax.item())
+            stats_c = stats.to(coll_dev)
+            allstats = [torch.empty_like(stats_c) for _ in range(world)]
+            clock.sync()
+            tg = time.perf_counter()
+            dist.all_gather(allstats, stats_c)
+            clock.sync()
+            gather_ms = (time.perf_counter() - tg) * 1e3
+            stats = torch.cat(allstats)
+            ranks_seen = dist.get_world_size()
+        if rank == 0:
+            value = world * B * K / elapsed
+            launch_us = gpu_us / nlaunch                # closed loop: one persistent launch = `chunk` steps of every env
+            steps_per_launch = K / nlaunch
+            window = {'episode_ends': int((env.episode_stats()[:, 0] < stats0[:, 0] + K).sum())}
+            if closed:
+                window['searches_per_env_per_step'] = float((env.plugins.t['plan_stat'][:, 0] - pstat0).double().mean()) / K
+            cfgd = {'workload': descr.format(B=B), 'name': args.workload, 'envs_per_gpu': B, 'agents': env.N,
+                    'grid': [env.cfg.W, env.cfg.H], 'rays': env.cfg.R, 'prologue_steps': args.prologue,
+                    'distinct_worlds_per_gpu': nw, 'auto_reset': True, 'kalman_trackers': 'on device', 'timed_window': window}
+            if closed:
+                cfgd.update({'gaze': 'Oxford on the device (yaw_planner.py:41-127), every step',
+                             'planner': 'Primitive on the device (traj_planner.py:78-233): replan_check every step, A* search '
+                                        'whenever the trajectory is empty',
+                             'launch_mode': ('one launch per stage per step' if args.no_persistent else
+                                             f'persistent: one launch per {args.chunk} steps, each wave loops over its own env'),
+                             'search_overflows': int(env.plugins.t['plan_stat'][:, 3].sum())})
+                kern = 'k_closed'
+                kname = 'k_closed (persistent closed loop: Oxford + Drone2DEnv2.step + Primitive)'
+                note = ('algorithmic bytes of the Drone2DEnv2.step stages (SURVEY 8(d), from this run\'s N / R / L / cells per agent) '
+                        'x envs x steps of one launch; the plugin phases are latency / issue bound, `step_kernel` is the step alone')
+            else:
+                cfgd.update({'gaze': 'fixed-seed U(-1,1) actions resident in HBM', 'planner': 'NoMove on the device',
+                             'launch_mode': 'd2d_rollout: one k_stages launch per step'})
+                kern, kname, note = 'k_stages', 'k_stages (fused Drone2DEnv2.step)', 'one launch = one step of every env'
+            line = {
+                'metric': 'env-steps/sec (batched) at 10 agents, map_id=1', 'value': value, 'unit': 'env-steps/s',
+                'n_gpus': world, 'steps': K, 'warmup': Wm, 'ms_per_step': elapsed * 1e3 / K,
+                'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+                'config': cfgd,
+                'roofline': roofline(kern, shape, algo, B, steps_per_launch, launch_us, {'kernel': kname, 'note': note}),
+                'valu': valu(kern, shape, B * steps_per_launch / (launch_us * 1e-6)),
+                'n_ranks_seen': ranks_seen, 'gather_ms': gather_ms,
+                'episode_stats': {'envs': int(stats.shape[0]), 'running_dynamic_collisions': int(stats[:, 3].sum()),
+                                  'mean_cells_discovered': float(stats[:, 6].double().mean())},
+            }
+    elif rank == 0:
+        line = {'metric': 'env-steps/sec (batched) at 10 agents, map_id=1', 'value': None, 'unit': 'env-steps/s',
+                'n_gpus': world, 'leg': args.leg, 'config': {'workload': descr.format(B=B), 'name': args.workload}}
 
     if rank == 0:
-        value = world * B * K / elapsed
-        launch_us = gpu_ms * 1e3 / nlaunch              # one persistent launch = `chunk` steps of every env
-        steps_per_launch = K / nlaunch
-        achieved = ALGO_BYTES_PER_ENV_STEP * B * steps_per_launch / (launch_us * 1e-6) / 1e9
-        line = {
-            'metric': 'env-steps/sec (batched) at 10 agents, map_id=1', 'value': value, 'unit': 'env-steps/s',
-            'n_gpus': world, 'steps': K, 'warmup': Wm, 'ms_per_step': elapsed * 1e3 / K,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': f'configs[1]: {B} batched envs per GPU x {args.agents} agents, agent_radius=15, '
-                                   '50x50 uint8 grid, 50 rays, map_id=1+env, Oxford gaze + Primitive planner',
-                       'envs_per_gpu': B, 'agents': env.N,
-                       'gaze': 'Oxford on the device (yaw_planner.py:41-127), every step',
-                       'planner': 'Primitive on the device (traj_planner.py:78-233): replan_check every step, A* search '
-                                  'whenever the trajectory is empty',
-                       'kalman_trackers': 'on device', 'auto_reset': True,
-                       'launch_mode': ('one launch per stage per step' if args.no_persistent else
-                                       f'persistent: one launch per {args.chunk} steps, each wave loops over its own env'),
-                       'searches_per_env': float(pstat[:, 0].double().mean()), 'search_overflows': int(pstat[:, 3].sum())},
-            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': _pmc('hbm_bytes_per_launch'),
-                         'kernel': 'k_closed (persistent closed loop: Oxford + Drone2DEnv2.step + Primitive)',
-                         'launch_us': launch_us, 'envs_per_launch': B, 'steps_per_launch': steps_per_launch,
-                         'algo_bytes_per_env_step': ALGO_BYTES_PER_ENV_STEP,
-                         'note': 'algorithmic bytes of the Drone2DEnv2.step stages (SURVEY 8(d)) x envs x steps of one launch; '
-                                 'the plugin phases are latency / issue bound, `step_kernel` is the step kernel alone'},
-            'valu': _valu('k_closed', B * steps_per_launch / (launch_us * 1e-6)),
-            'episode_stats': {'envs': int(stats.shape[0]), 'running_dynamic_collisions': int(stats[:, 3].sum()),
-                              'mean_cells_discovered': float(stats[:, 6].double().mean())},
-        }
-        if not args.no_step_kernel:       # after the timed region, on its own state
-            env_hot = vec_env.VecDrone2DEnv(params, B, device=device, planner='external', env_offset=rank * B, worlds=worlds)
-            line['step_kernel'] = step_kernel_leg(torch, env_hot, params, rank, device, B)
-        if not args.no_cpu_baseline and world == 1:
-            line['cpu_baseline'] = cpu_baseline(pkg, params)
+        sshape = {'workload': args.workload, 'envs': B}
+        if args.leg in ('all', 'step'):       # after the timed region, on its own state
+            env_hot = vec_env.VecDrone2DEnv(params, B, device=device, planner='external' if closed else 'NoMove',
+                                            env_offset=rank * B, worlds=worlds)
+            us, reps = stage_leg(torch, clock, env_hot, params, rank, B, 'step')
+            line['step_kernel'] = {
+                'kernel': 'k_stages (fused Drone2DEnv2.step: agents, raycast, dynamic grid, trackers, control, collision, obs)',
+                'inputs': 'fixed-seed U(-1,1) gaze actions and synthetic waypoint heads resident in HBM (replay mode)',
+                'launches': 500, 'repetitions_us': reps, 'env_steps_per_s': B / (us * 1e-6),
+                'roofline': roofline('k_stages', sshape, algo, B, 1, us), 'valu': valu('k_stages', sshape, B / (us * 1e-6))}
+            del env_hot
+        if args.leg in ('all', 'raycast'):
+            # the raycast stage on mid-episode worlds: after the timed region on the closed-loop state, else after a short flight
+            if args.leg == 'raycast':
+                run(min(args.prologue, 100))
+            us, reps = stage_leg(torch, clock, env, params, rank, B, 'raycast')
+            rb = algo_bytes(env.cfg, env.state.agent_unit, 'raycast')
+            line['raycast_stage'] = {
+                'kernel': 'k_stages with D2D_ST_AGENTS | D2D_ST_RAYCAST (d2d_run_stages): Agent.step + Raycast.castRays, utils.py:472-493,593-713',
+                'state': 'the worlds as the flight above left them (drones spread over their maps, explored maps part filled)',
+                'launches': 500, 'repetitions_us': reps, 'env_steps_per_s': B / (us * 1e-6),
+                'roofline': roofline('raycast_stage', sshape, rb, B, 1, us,
+                                     {'note': 'bytes: 36 N agents + N hit mask + R S ground-truth reads + R (S - 1) drone-map writes + 44 B pose'})}
+        if not args.no_cpu_baseline and world == 1 and args.leg == 'all':
+            line['cpu_baseline'] = cpu_baseline(pkg, params, closed)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

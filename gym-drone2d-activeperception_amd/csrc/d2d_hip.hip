@@ -1308,7 +1308,8 @@ __global__ void k_tan(const double *in, double *out, long long n) {
 // with only wave-local fences between the phases.  Envs are independent, so nothing has to wait at a kernel
 // boundary for the slowest env of the batch: a 99-expansion search (up to ~1 ms) costs that env's wave its own
 // time instead of stalling 4095 others every step, and a step costs no launches at all.
-// Only for the specialised default geometry (SPEC 1 / 2); other configurations take the launch-per-stage path.
+// Instantiated like the step kernel (SPEC 0-3); a configuration whose phases do not fit the LDS budget of one workgroup
+// takes the launch-per-stage path.
 // ------------------------------------------------------------------------------------------------
 // The launch arguments (four structs of pointers) are parked once in device memory (d2d_plan.launch_args) and every
 // phase is a NON-INLINED function that reads what it needs through scalar loads: inlined into one loop body the
@@ -1321,6 +1322,7 @@ struct ClosedArgs {
   d2d_state init;
   int on_done, nsteps;
 };
+static_assert(sizeof(ClosedArgs) <= D2D_LAUNCH_ARGS_BYTES, "d2d_plan.launch_args (D2D_LAUNCH_ARGS_BYTES) is too small for the parked launch arguments");
 
 __global__ void k_closed_args(ClosedArgs *dst, d2d_cfg c, d2d_state s, d2d_plan p, d2d_state init, int on_done, int nsteps) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {

@@ -150,8 +150,9 @@ def pairwise_sum_host(a, leaves, prog):
 # ---------------------------------------------------------------------------------------------------
 # tables
 # ---------------------------------------------------------------------------------------------------
-def build_tables(params, cfg):
-    """Scalars + numpy tables of `d2d_plan`, each computed as the reference computes it."""
+def build_tables(params, cfg, need_acos=True):
+    """Scalars + numpy tables of `d2d_plan`, each computed as the reference computes it.  `need_acos`: the arccos decision
+    window of the Oxford stage (view ranges it cannot describe only matter when that stage runs)."""
     p = params
     t = {}
     # Primitive.__init__, traj_planner.py:95-107
@@ -188,7 +189,7 @@ def build_tables(params, cfg):
     offs = leaves[:, 0]
     t['pw_rowleaf'] = np.array([int(np.searchsorted(offs, i * cfg.H, side='right') - 1) for i in range(cfg.W)], dtype=np.int32)
     half = math.radians(p.drone_view_range / 2)                                  # :72
-    key_lo, mask = acos_window(half)
+    key_lo, mask = acos_window(half) if need_acos else (0, 0)
     # successors of one expansion satisfy |v + 2 a| < vmax: at most this many lattice points of u_space
     step = float(u_space[1] - u_space[0]) if len(u_space) > 1 else 1.0
     side = int(2 * p.drone_max_speed / (horizon * step)) + 2
@@ -211,7 +212,7 @@ class PluginState:
     def __init__(self, params, cfg, device, tracker_radius, planner='Primitive', gaze='Oxford', tables=None):
         self.cfg = cfg
         self.device = torch.device(device)
-        sc, tb = tables if tables is not None else build_tables(params, cfg)
+        sc, tb = tables if tables is not None else build_tables(params, cfg, need_acos=(gaze == 'Oxford'))
         self.scalars, self.tables_np = sc, tb
         self.planner = A.PLAN_PRIMITIVE if planner == 'Primitive' else A.PLAN_NONE
         self.gaze = A.GAZE_OXFORD if gaze == 'Oxford' else A.GAZE_NONE

@@ -5,10 +5,10 @@ on top of the batched device step.
     env.reset() -> {}                    # drone_v2.py:259-261
     obs, 0, done, info = env.step(a)     # old-gym 4-tuple, drone_v2.py:257
 
-The world lives in HBM (a VecDrone2DEnv of one env); `step` is d2d_step (NoMove) or d2d_perceive ->
-host planner plugin -> d2d_act (any planner with the reference interface).  The objects scripts reach
-into are thin proxies over a host mirror refreshed once per step, and every attribute the reference's
-scripts mutate writes through to the device:
+The world lives in HBM (a VecDrone2DEnv of one env); `step` is d2d_step (NoMove), d2d_perceive -> d2d_plan_stage ->
+d2d_act (Primitive on the device) or d2d_perceive -> host planner plugin -> d2d_act (any other class with the
+reference interface).  The objects scripts reach into are thin proxies over a host mirror refreshed by one packed
+copy per step, and every attribute the reference's scripts mutate writes through to the device:
     env.drone.x / .y / .yaw / .velocity / .radius        (validation_shape.py:79-80, survivability sweeps)
     env.agents[i].position / .pref_velocity / .radius     (validation_speed.py:135-138)
     env.drone.map.grid_map, env.map_gt.grid_map, env.drone.trackers[k].active / .mu_upds / .estimate_pos
@@ -18,11 +18,16 @@ import torch
 
 from . import _abi as A
 from .params import with_defaults
+from .gaze import DeviceAction
 from .planners import planner_list
 from .vec_env import VecDrone2DEnv
 
+_NP = {torch.float64: np.float64, torch.float32: np.float32, torch.int32: np.int32, torch.uint8: np.uint8}
+
 try:                                   # gym is optional: the reference pins gym 0.21, this image has none
     import gym as _gym
+    if not (hasattr(_gym, '__version__') and hasattr(_gym.spaces.Dict, '__getitem__')):
+        raise ImportError('not a real gym (an import-time stub of a harness)')
     _EnvBase = _gym.Env
 except Exception:                      # pragma: no cover
     _gym = None
@@ -208,11 +213,20 @@ class DroneProxy:
 
 
 class Drone2DEnv2(_EnvBase):
+    """Three step paths, chosen by the class `planner_list[params.planner]` resolves to:
+      device NoMove     one fused launch (d2d_step)
+      device Primitive  d2d_perceive -> d2d_plan_stage -> d2d_act queued back to back, no host in between
+      host plugin       d2d_perceive -> planner.replan_check / plan on the host -> d2d_act
+    and ONE packed device-to-host copy per step refreshes the mirror the proxies read (two on the host-plugin path,
+    whose planner needs this step's perception)."""
     metadata = {'render.modes': []}
+    _MIRROR_STATE = ('agents', 'drone', 'target', 'kf', 'agent_unit', 'counters', 'kf_len', 'newly', 'obs_yaw',
+                     'gt', 'dmap', 'active', 'hit', 'flags', 'obs_local')          # 8-byte fields first: aligned views
+    _MIRROR_PLUGIN = ('trk_radius', 'traj_hdr')
 
-    def __init__(self, params, device='cuda:0', backend=None, _shared=None):
+    def __init__(self, params, device='cuda:0', backend=None):
         self._device, self._backend = device, backend
-        self._shared = _shared            # (VecDrone2DEnv, index): this env is slot `index` of a shared batch (batch.py)
+        self._render_warned = False
         self._build(params)
 
     # ------------------------------------------------------------------------------------------
@@ -221,18 +235,24 @@ class Drone2DEnv2(_EnvBase):
         p = self.params
         if p.motion_profile != 'CVM':
             raise NotImplementedError('motion_profile RVO is outside the accelerated hot path (SURVEY.md section 2)')
-        if p.planner not in planner_list:
-            raise KeyError(f'unknown planner {p.planner!r}; known: {sorted(planner_list)}')
-        self._device_nomove = (p.planner == 'NoMove') and self._shared is None
-        if self._shared is None:
-            self._vec, self._slot = VecDrone2DEnv(p, 1, device=self._device, backend=self._backend,
-                                                  planner='NoMove' if self._device_nomove else 'external'), 0
-        else:
-            self._vec, self._slot = self._shared
+        planner_cls = planner_list[p.planner]                       # KeyError for an unknown name, as the reference
+        on_device = bool(getattr(planner_cls, 'on_device', False))
+        self._mode = ('fused' if p.planner == 'NoMove' else 'device') if on_device else 'host'
+        want_gaze = on_device and p.gaze_method == 'Oxford'
+        plugins = self._mode == 'device' or want_gaze
+        self._vec = VecDrone2DEnv(p, 1, device=self._device, backend=self._backend,
+                                  planner=p.planner if on_device else 'external', device_plugins=plugins,
+                                  gaze=('Oxford' if want_gaze else 'external') if plugins else None)
+        self._slot = 0
+        self._device_gaze = want_gaze
         self._backend = self._vec.backend
         self._tracker_radius = self._vec.tracker_radius[self._slot].numpy().copy()
         from . import host_init
         self._group = host_init.init_world(p)['group'] if self._vec.N else np.zeros(0, dtype=np.int64)
+        # utils.py:605 draws the measurement noise from the global numpy stream the env seeded (drone_v2.py:80) and
+        # advanced by the 100 draws of its init (drone_v2.py:51-55): the same stream, kept private to this env
+        self._noise_rng = np.random.RandomState(p.map_id)
+        self._noise_rng.rand(100)
         self.dt = p.dt
         self.steps = 0
         self.max_steps = p.max_flight_time / p.dt
@@ -240,12 +260,13 @@ class Drone2DEnv2(_EnvBase):
         self.tracker_buffer = []
         self.target_list = [list(np.asarray(t).ravel()) for t in p.target_list]
         self.obstacles = []
-        self._mirror = {}
+        self.screen = None                      # scripts assign / read it around render (survivability_calculator.py:38-39)
+        self._mirror, self._pull_count = {}, 0
         self._pull()
         self.drone = DroneProxy(self)
         self.agents = [AgentProxy(self, k) for k in range(self._vec.N)]
         self.map_gt = GridProxy(self, 'gt', p.map_scale, p.map_size)
-        self.planner = planner_list[p.planner](self.drone, p)
+        self.planner = planner_cls(self.drone, p)
         self.state_machine = A.SM_WAIT_FOR_GOAL
         self.fail_count = 0
         BoxT, DictT = _spaces()
@@ -260,16 +281,27 @@ class Drone2DEnv2(_EnvBase):
                              shape=(1, L, L), dtype=np.float32)})
         self.info = self._info(0, 0, 0)
 
-    def _pull(self):
-        """One D2H refresh of the host mirror (the env is tiny: a few KB)."""
-        self._vec.sync()
-        s = self._vec.state
-        for k in ('agents', 'agent_unit', 'gt', 'dmap', 'drone', 'target', 'counters', 'active', 'kf', 'kf_len',
-                  'hit', 'flags', 'obs_local', 'obs_yaw', 'newly'):
-            self._mirror[k] = s.t[k][self._slot].cpu().numpy().copy()
+    def _pull(self, only=None):
+        """ONE device-to-host copy: the mirrored fields of this env packed into a byte buffer on the device."""
+        vec, slot = self._vec, self._slot
+        parts = [(k, vec.state.t[k][slot]) for k in (only or self._MIRROR_STATE)]
+        if vec.plugins is not None and only is None:
+            parts += [(k, vec.plugins.t[k][slot]) for k in self._MIRROR_PLUGIN]
+        flat = torch.cat([t.reshape(-1).view(torch.uint8) for _, t in parts]).cpu().numpy()
+        off = 0
+        for k, t in parts:
+            n = t.numel() * t.element_size()
+            self._mirror[k] = np.frombuffer(flat[off:off + n].tobytes(), dtype=_NP[t.dtype]).reshape(tuple(t.shape)).copy()
+            off += n
+        if 'trk_radius' in self._mirror:
+            self._tracker_radius = self._mirror['trk_radius']
+        self._pull_count += 1
 
     def _push(self, field, arr):
         self._vec.state.t[field][self._slot].copy_(torch.from_numpy(np.ascontiguousarray(arr)))
+
+    def _push_plugin(self, field, arr):
+        self._vec.plugins.t[field][self._slot].copy_(torch.from_numpy(np.ascontiguousarray(arr)))
 
     def _info(self, col, dead, frz):
         return {'drone': self.drone, 'trajectory': self.planner.trajectory, 'state_machine': self.state_machine,
@@ -278,8 +310,6 @@ class Drone2DEnv2(_EnvBase):
 
     # ------------------------------------------------------------------------------------------
     def reset(self):
-        if self._shared is not None:
-            raise RuntimeError('reset the HostPluginBatch, not its slots')
         self._build(self.params)
         return {}
 
@@ -288,7 +318,7 @@ class Drone2DEnv2(_EnvBase):
         (plan_ok, has_waypoint, waypoint[6]) and pushes the planner's target to the device."""
         # set_target as the device's state machine just did (drone_v2.py:160-163)
         self.planner.target = np.array([self._mirror['target'][0], self._mirror['target'][1], 0., 0.])
-        _, swep_map = self.planner.replan_check(self.drone)            # drone_v2.py:194
+        self.planner.replan_check(self.drone)                          # drone_v2.py:194
         ok = bool(self.planner.plan(self.drone, self.dt))              # drone_v2.py:197
         tr = self.planner.trajectory
         wp = np.zeros(6)
@@ -299,7 +329,7 @@ class Drone2DEnv2(_EnvBase):
             wp[4:6] = np.asarray(tr.accelerations[0], dtype=np.float64).ravel()
             tr.pop()                                                   # utils.py:739
         tgt = np.asarray(self.planner.target, dtype=np.float64).ravel()
-        self._push('target', tgt[:2])                                  # planners may move the target (NoMove does)
+        self._push('target', tgt[:2])                                  # planners may move the target
         return ok, has_wp, wp
 
     def _finish_step(self):
@@ -310,7 +340,8 @@ class Drone2DEnv2(_EnvBase):
         self.state_machine = int(c[A.C_SM])
         self.fail_count = int(c[A.C_FAIL])
         self.tracked_agent = int(c[A.C_TRACKED])
-        self.target_list = self.target_list[-max(int(c[A.C_NTGT] - c[A.C_TGT_NEXT]), 0):] if c[A.C_NTGT] > c[A.C_TGT_NEXT] else []
+        left = int(c[A.C_NTGT] - c[A.C_TGT_NEXT])
+        self.target_list = self.target_list[-left:] if left > 0 else []
         nbuf, nts = int(c[A.C_BUF_N]), int(c[A.C_BUF_TS])
         self.tracker_buffer = [_ArchivedTracker(nts - (nbuf - 1))] + [_ArchivedTracker(1)] * (nbuf - 1) if nbuf else []
         done = bool(f[A.F_DONE])
@@ -319,26 +350,53 @@ class Drone2DEnv2(_EnvBase):
                  'yaw_angle': np.array([m['obs_yaw']], dtype=np.float32).flatten()}
         return state, 0, done, self.info
 
-    def step(self, a):
-        if self._shared is not None:
-            raise RuntimeError('this env is a slot of a HostPluginBatch: step the batch, not the slot')
-        a_val = float(np.asarray(a, dtype=np.float64).ravel()[0])
+    def _perceive(self):
+        """d2d_perceive; with measurement noise (var_cam != 0) split after the raycast, because the reference draws
+        np.random.randn(2) for the agents the rays hit, in agent order (utils.py:603-605)."""
         vec = self._vec
-        if self._device_nomove:
-            vec.step(a_val)
-            self._pull()
-            self.planner.target = np.array([-1, -1, 0, 0])            # traj_planner.py:72
-        else:
-            vec.perceive()
+        if self.params.var_cam == 0 or vec.N == 0:
+            vec.backend.perceive(vec.cfg, vec._st)
+            return
+        vec.backend.run_stages(vec.cfg, vec._st, A.ST_FSM | A.ST_AGENTS | A.ST_RAYCAST)
+        self._pull(only=('hit',))
+        noise = np.zeros((1, vec.N, 2))
+        for k in np.nonzero(self._mirror['hit'])[0]:
+            noise[0, k] = self._noise_rng.randn(2)
+        vec.set_noise(noise)
+        vec.backend.run_stages(vec.cfg, vec._st, A.ST_DYNGRID | A.ST_TRACKER)
+
+    def step(self, a):
+        vec = self._vec
+        if not (isinstance(a, DeviceAction) and a.fresh_for(self)):    # else: d2d_gaze_stage already wrote the action
+            vec._set_action(float(a) if isinstance(a, DeviceAction) else float(np.asarray(a, dtype=np.float64).ravel()[0]))
+        if self._mode == 'host':
+            self._perceive()
             self._pull()
             ok, has_wp, wp = self._plan_phase()
             vec.set_plan([ok], [has_wp], wp[None])
-            vec.act(a_val)
+        elif self._mode == 'device':
+            self._perceive()
+            vec.backend.plan_stage(vec.cfg, vec._st, vec._plan)
+        elif self.params.var_cam != 0 and vec.N:
+            self._perceive()
+        else:
+            vec.backend.step(vec.cfg, vec._st)                         # fused: perceive + act in one launch
             self._pull()
+            return self._finish_step()
+        vec.backend.act(vec.cfg, vec._st)
+        self._pull()
         return self._finish_step()
 
     def render(self, mode='human'):
-        raise NotImplementedError('rendering (pygame) is outside the accelerated hot path')
+        """envs/drone_v2.py:263-303 is display only (pygame).  The reference's Params default to render=True and its
+        Experiment.run calls env.render() every step (utils.py:75-77, experiment.py:105-106), so the default
+        invocation has to survive it: headless no-op, one warning."""
+        if not self._render_warned:
+            import warnings
+            warnings.warn('Drone2DEnv2.render(): the accelerated env is headless, render() does nothing '
+                          '(pass --debug / render=False to silence this)', RuntimeWarning, stacklevel=2)
+            self._render_warned = True
+        return None
 
 
 def register():

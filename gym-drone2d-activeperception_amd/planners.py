@@ -1,66 +1,96 @@
-"""--planner plugin surface (reference: traj_planner.py).
+"""--planner plugin surface (reference: traj_planner.py; registry envs/drone_v2.py:70-75).
 
-Interface kept from the reference so its callers and any third-party planner drop in:
+What the reference's callers touch is kept:
     planner = planner_list[params.planner](drone, params)
+    planner.trajectory (.positions / .velocities / .accelerations, len(), pop(), clear()) ; planner.target ;
     planner.set_target(xy) ; planner.plan(drone, dt) -> bool ; planner.replan_check(drone) -> (bool, swep_map)
-    planner.trajectory (.positions / .velocities / .accelerations, len(), pop(), clear()) ; planner.target
 
-`NoMove` also exists on the device (D2D_PLANNER_NOMOVE).  `Primitive` here is a host restatement of the
-reference's motion-primitive A* (traj_planner.py:78-233): it runs between the two halves of the device
-step (VecDrone2DEnv.perceive / act) and sees the drone's explored map and tracker estimates through the
-same attribute names the reference planner reads (drone.map.get_grid, drone.trackers[k].active /
-.estimate_pos / .radius).  MPC needs the proprietary FORCESPRO solver and Jerk_Primitive is not part of
-this hot path; asking for them raises.
+`Primitive` and `NoMove` ARE the device stages (csrc/d2d_plugins.h `plan_env`, D2D_PLANNER_NOMOVE): the objects
+registered here hold no algorithm, they are views of the env's device-resident planner state -- `env.step`
+runs `d2d_perceive -> d2d_plan_stage -> d2d_act` without coming back to the host in between.  Any other class
+with the reference's interface (the reference's own `traj_planner.Primitive`, a third-party planner) is a host
+plugin: register it with `register_planner` and `env.step` calls its replan_check / plan between the two
+device halves of the step.  Names this registry does not know are looked up in the reference's `traj_planner`
+module when that is importable (i.e. when this package sits inside the reference checkout).
 """
 import numpy as np
-from numpy.linalg import norm
 
 
-class Trajectory2D:
-    """utils.py:280-298."""
+class HostTrajectory:
+    """Plain waypoint lists for host planner plugins (the surface of utils.py:280-294)."""
 
     def __init__(self):
-        self.positions, self.velocities, self.accelerations = [], [], []
-
-    def pop(self):
-        self.positions.pop(0)
-        self.velocities.pop(0)
-        self.accelerations.pop(0)
+        self.clear()
 
     def clear(self):
         self.positions, self.velocities, self.accelerations = [], [], []
+
+    def pop(self):
+        for seq in (self.positions, self.velocities, self.accelerations):
+            del seq[0]
 
     def __len__(self):
         return len(self.positions)
 
 
+class TrajectoryView:
+    """The device planner's stored trajectory (`d2d_plan.traj`, `traj_hdr`) behind the reference's trajectory
+    surface.  Waypoints are fetched from the device when somebody looks at them (a host gaze policy, a script),
+    once per step; `len()` comes from the header the env mirrors every step anyway."""
+
+    def __init__(self, env):
+        self._env = env
+        self._rows, self._stamp = None, None
+
+    def _load(self):
+        env = self._env
+        stamp = (env._pull_count, tuple(int(v) for v in env._mirror['traj_hdr']))
+        if self._stamp != stamp:
+            head, stored = stamp[1]
+            self._rows = env._vec.plugins.t['traj'][env._slot, head:stored].cpu().numpy().copy()
+            self._stamp = stamp
+        return self._rows
+
+    def __len__(self):
+        head, stored = self._env._mirror['traj_hdr']
+        return int(stored - head)
+
+    @property
+    def positions(self):
+        return [r[0:2].copy() for r in self._load()]
+
+    @property
+    def velocities(self):
+        return [r[2:4].copy() for r in self._load()]
+
+    @property
+    def accelerations(self):
+        return [np.array([0, 0]) for _ in range(len(self))]        # traj_planner.py:214
+
+    def pop(self):
+        hdr = self._env._mirror['traj_hdr']
+        if hdr[1] - hdr[0] > 0:
+            hdr[0] += 1
+            self._env._push_plugin('traj_hdr', hdr)
+
+    def clear(self):
+        hdr = self._env._mirror['traj_hdr']
+        hdr[:] = 0
+        self._env._push_plugin('traj_hdr', hdr)
+
+
 class Planner:
-    """traj_planner.py:18-66."""
+    """Base of the HOST planner plugins: the attributes env.step reads (traj_planner.py:18-26)."""
+    on_device = False
 
     def __init__(self, drone, params):
-        self.trajectory = Trajectory2D()
+        self.trajectory = HostTrajectory()
         self.params = params
         self.target = np.array([drone.x, drone.y, 0, 0])
 
     def set_target(self, target):
         self.target = np.zeros(4)
         self.target[:2] = target
-
-    def is_free(self, position, t, occupancy_map, trackers):
-        """Five-probe static test at drone_radius + 10, then every active tracker's constant-velocity
-        prediction at time t (traj_planner.py:28-59)."""
-        if np.isnan(position).any():
-            return False
-        d = self.params.drone_radius + 10
-        x, y = position[0], position[1]
-        for qx, qy in ((x - d, y), (x, y), (x + d, y), (x, y - d), (x, y + d)):
-            if occupancy_map.get_grid(qx, qy) == 1:
-                return False
-        for tr in trackers:
-            if tr.active:
-                if norm(position - tr.estimate_pos(t)) <= self.params.drone_radius + tr.radius + 5 + self.params.var_cam:
-                    return False
-        return True
 
     def plan(self, drone, update_t):
         raise NotImplementedError('No planner implemented!')
@@ -69,139 +99,80 @@ class Planner:
         raise NotImplementedError('No replan checker implemented!')
 
 
-class NoMove(Planner):
-    """traj_planner.py:68-76."""
+class _DevicePlanner:
+    """A planner that runs as a device stage of env.step; this object only exposes its state."""
+    on_device = True
 
-    def plan(self, drone, dt):
-        self.target = np.array([-1, -1, 0, 0])
-        return True
+    def __init__(self, drone, params):
+        env = getattr(drone, '_env', None)
+        if env is None:
+            raise TypeError(f'{type(self).__name__} runs on the device inside Drone2DEnv2.step; it is built by the env '
+                            '(planner_list[params.planner](env.drone, params)), not for a free-standing drone')
+        self._env = env
+        self.params = params
+
+    @property
+    def target(self):
+        t = self._env._mirror['target']
+        return np.array([t[0], t[1], 0., 0.])
+
+    @target.setter
+    def target(self, value):
+        self.set_target(np.asarray(value, dtype=np.float64).ravel()[:2])
+
+    def set_target(self, target):
+        t = np.asarray(target, dtype=np.float64).ravel()[:2].copy()
+        self._env._mirror['target'] = t
+        self._env._push('target', t)
+
+    def plan(self, drone, update_t):
+        raise RuntimeError(f'{type(self).__name__}.plan runs inside env.step on the device (d2d_plan_stage)')
 
     def replan_check(self, drone):
-        return False, drone.map.grid_map
+        raise RuntimeError(f'{type(self).__name__}.replan_check runs inside env.step on the device (d2d_plan_stage)')
 
 
-class _Node:
-    __slots__ = ('position', 'velocity', 'cost', 'total_cost', 'index', 'parent_index', 'coeff', 'itr')
-
-    def __init__(self, pos, vel, cost, target, parent_index, coeff, itr):
-        self.position, self.velocity, self.cost = pos, vel, cost
-        self.parent_index, self.coeff, self.itr = parent_index, coeff, itr
-        self.total_cost = cost + 0.5 * norm(pos - target) + 0.1 * norm(vel)       # traj_planner.py:88
-        self.index = (round(pos[0]) // 10, round(pos[1]) // 10, round(vel[0]), round(vel[1]))   # :93
-
-
-class Primitive(Planner):
-    """Motion-primitive A* (traj_planner.py:78-233): 8 x 8 constant accelerations held for 2 s, at most
-    99 expansions, 8 collision samples per primitive, trajectory re-sampled every dt."""
+class NoMove(_DevicePlanner):
+    """traj_planner.py:68-76 as D2D_PLANNER_NOMOVE: always succeeds, never moves, target (-1, -1)."""
 
     def __init__(self, drone, params):
         super().__init__(drone, params)
-        a, v = params.drone_max_acceleration, params.drone_max_speed
-        self.u_space = np.arange(-a, a, 0.4 * v - 5) if v <= 40 else np.arange(-a, a, 4)      # :98-101
-        self.dt = 2
-        self.sample_num = v * self.dt // params.map_scale                                    # :104
-        self.target = np.array([drone.x, drone.y, 0, 0])
-        self.search_threshold = 10
-        self.phi = 10
+        self.trajectory = HostTrajectory()
 
-    @staticmethod
-    def _pos(coeff, t):
-        return np.around(np.array([1, t, t ** 2]) @ coeff.T)                                 # :121
 
-    @staticmethod
-    def _vel(coeff, t):
-        return np.array([1, 2 * t]) @ coeff[:, 1:].T                                         # :122
+class Primitive(_DevicePlanner):
+    """traj_planner.py:78-233 as the device stage `plan_env` (csrc/d2d_plugins.h): replan_check, the
+    motion-primitive A* and the head waypoint all run between d2d_perceive and d2d_act."""
 
-    def plan(self, drone, update_t):
-        if len(self.trajectory) != 0:
+    def __init__(self, drone, params):
+        super().__init__(drone, params)
+        self.trajectory = TrajectoryView(self._env)
+
+
+class _Registry(dict):
+    """Name -> class.  Unknown names fall back to the reference's own module when it is importable."""
+    module, what = 'traj_planner', 'planner'
+
+    def __missing__(self, name):
+        try:
+            mod = __import__(self.module)
+            cls = getattr(mod, name)
+        except Exception:
+            raise KeyError(f'unknown {self.what} {name!r}: known here {sorted(self)}; other names resolve through the '
+                           f"reference's {self.module}.py when it is importable") from None
+        return cls
+
+    def __contains__(self, name):
+        if dict.__contains__(self, name):
             return True
-        tgt = self.target[:2]
-        self.trajectory = Trajectory2D()
-        start = _Node(np.array([drone.x, drone.y]), drone.velocity, 0, tgt, -1, None, 0)
-        open_set, closed_set = {start.index: start}, {}
-        grid, trackers = drone.map, drone.trackers
-        H = self.dt
-        goal, itr = None, 0
-        while True:
-            itr += 1
-            if len(open_set) == 0 or itr >= 100:                                             # :149
-                break
-            cid = min(open_set, key=lambda o: open_set[o].total_cost)
-            cur = open_set[cid]
-            if norm(cur.position - tgt) <= self.search_threshold:
-                goal = cur
-                break
-            del open_set[cid]
-            closed_set[cid] = cur
-            succ = []
-            px, py = cur.position[0], cur.position[1]
-            vx, vy = cur.velocity[0], cur.velocity[1]
-            for ax in self.u_space:
-                for ay in self.u_space:
-                    v_end = np.array([1, 2 * H]) @ np.array([[vx, vy], [ax / 2, ay / 2]])
-                    if not (norm(v_end) < self.params.drone_max_speed):
-                        continue
-                    coeff = np.array([[px, vx, ax / 2], [py, vy, ay / 2]])
-                    ok = True
-                    for t in np.arange(0, H, H / self.sample_num):
-                        if not self.is_free(self._pos(coeff, t), t + cur.itr * H, grid, trackers):
-                            ok = False
-                            break
-                    if ok:
-                        p_end = np.around(np.array([1, H, H ** 2]) @ np.array([[px, py], [vx, vy], [ax / 2, ay / 2]]))
-                        succ.append(_Node(p_end, v_end, cur.cost + (ax ** 2 + ay ** 2) / 100 + 10, tgt,
-                                          cur.index, coeff, cur.itr + 1))
-            for n in succ:
-                if n.index in closed_set:
-                    continue
-                if n.index not in open_set or open_set[n.index].cost > n.cost:
-                    open_set[n.index] = n
-        if goal is None:
+        try:
+            self.__missing__(name)
+            return True
+        except KeyError:
             return False
-        node = goal
-        ts = np.arange(H, 0, -update_t)
-        while node is not start:
-            self.trajectory.positions.extend([self._pos(node.coeff, t) for t in ts])
-            self.trajectory.velocities.extend([self._vel(node.coeff, t) for t in ts])
-            self.trajectory.accelerations.extend([np.array([0, 0]) for _ in ts])
-            node = closed_set[node.parent_index]
-        self.trajectory.positions.reverse()
-        self.trajectory.velocities.reverse()
-        return True
-
-    def replan_check(self, drone):
-        """traj_planner.py:220-233 (swep_map is uint8, so i * dt truncates)."""
-        occ = drone.map.grid_map
-        swep = np.zeros_like(occ)
-        s, dt = self.params.map_scale, self.params.dt
-        for i, pos in enumerate(self.trajectory.positions):
-            swep[int(pos[0] // s), int(pos[1] // s)] = i * dt
-            for tr in drone.trackers:
-                if tr.active and norm(tr.estimate_pos(i * dt) - pos) <= self.params.drone_radius + tr.radius:
-                    self.trajectory.clear()
-                    return True, swep
-        if np.sum(np.where(occ == 1, 1, 0) * swep) > 0:
-            self.trajectory.clear()
-            return True, swep
-        return False, swep
 
 
-def _unavailable(name, why):
-    class _U(Planner):
-        def __init__(self, drone, params):
-            raise NotImplementedError(f'planner {name!r}: {why}')
-    _U.__name__ = name
-    return _U
-
-
-planner_list = {
-    'Primitive': Primitive,
-    'NoMove': NoMove,
-    'MPC': _unavailable('MPC', 'needs the proprietary FORCESPRO solver (unusable in the reference too, '
-                               'traj_planner.py:14-16,243)'),
-    'Jerk_Primitive': _unavailable('Jerk_Primitive', 'not part of the accelerated hot path; register your own class '
-                                                     'with planners.register_planner'),
-}
+planner_list = _Registry(Primitive=Primitive, NoMove=NoMove)
 
 
 def register_planner(name, cls):

@@ -145,17 +145,14 @@ class VecDrone2DEnv:
         assert actions.shape == (T, self.num_envs)
         if pin is not None:
             pin = torch.as_tensor(pin, dtype=torch.float64, device=self.device).contiguous()
-        coll = torch.zeros((T, self.num_envs), dtype=torch.uint8, device=self.device) if collisions else None
+        coll = torch.empty((T, self.num_envs), dtype=torch.uint8, device=self.device) if collisions else None
         S = max(1, min(int(streams), self.num_envs))
         if S == 1 or self.device.type != 'cuda':
             self.backend.rollout(self.cfg, self._st, T, actions, pin, coll)
             return coll
         # sub-batch i owns envs [lo, hi): its own cfg (B = hi - lo) and state struct (every pointer offset by lo)
         import copy
-        import ctypes as C
         cur = torch.cuda.current_stream(self.device)
-        ready = torch.cuda.Event()
-        ready.record(cur)
         bounds = [(self.num_envs * i) // S for i in range(S + 1)]
         subs = []
         for i in range(S):
@@ -169,22 +166,28 @@ class VecDrone2DEnv:
                 t = self.state.noise if name == 'noise' else self.state.t.get(name)
                 base = getattr(self._st, name)
                 setattr(st, name, None if (t is None or not base) else base + lo * t.stride(0) * t.element_size())
-            # the step-t row of a sub-batch is not contiguous in [T, B]: give each sub-batch its own copies
+            # the step-t row of a sub-batch is not contiguous in [T, B]: give each sub-batch its own copies (made on the
+            # current stream, like everything the caller queued before this call)
             a_i = actions[:, lo:hi].contiguous()
-            c_i = torch.zeros((T, hi - lo), dtype=torch.uint8, device=self.device) if collisions else None
-            subs.append((lo, hi, cfg, st, a_i, None if pin is None else pin[lo:hi].contiguous(), c_i, torch.cuda.Stream(self.device)))
+            p_i = None if pin is None else pin[lo:hi].contiguous()
+            # every step writes its whole row of collision flags: no fill, so nothing on the current stream can land
+            # after a side stream's first step
+            c_i = torch.empty((T, hi - lo), dtype=torch.uint8, device=self.device) if collisions else None
+            subs.append((lo, hi, cfg, st, a_i, p_i, c_i, torch.cuda.Stream(self.device)))
+        # the side streams start after EVERYTHING queued so far on the current stream, the per-sub-batch copies included
+        ready = torch.cuda.Event()
+        ready.record(cur)
         for lo, hi, cfg, st, a_i, p_i, c_i, stream in subs:
             stream.wait_event(ready)
             with torch.cuda.stream(stream):
                 self.backend.rollout(cfg, st, T, a_i, p_i, c_i)
+            for t_ in (a_i, p_i, c_i):       # allocated on the current stream, consumed on `stream`
+                if t_ is not None:
+                    t_.record_stream(stream)
         for lo, hi, cfg, st, a_i, p_i, c_i, stream in subs:
             cur.wait_stream(stream)
             if collisions:
-                with torch.cuda.stream(cur):
-                    coll[:, lo:hi] = c_i
-            for t_ in (a_i, p_i, c_i):
-                if t_ is not None:
-                    t_.record_stream(cur)
+                coll[:, lo:hi] = c_i
         return coll
 
     def _result(self):

@@ -253,7 +253,9 @@ typedef struct d2d_plan {
                            implementation's (the oracle keeps records, the HIP library planes) */
   int32_t D2D_AS *hash;        /* [B][hash_cap] */
   void *launch_args;    /* >= D2D_LAUNCH_ARGS_BYTES of device memory where the persistent closed-loop launch parks its
-                           arguments (NULL: d2d_closed_loop launches every stage of every step separately) */
+                           arguments (NULL: d2d_closed_loop launches every stage of every step separately).  Every
+                           d2d_closed_loop call on this d2d_plan rewrites the buffer on its stream: a d2d_plan (like the
+                           state buffers) belongs to ONE stream at a time */
   /* ---- diagnostics ---- */
   int32_t D2D_AS *plan_stat;   /* [B][4] searches run, expansions of the last search, nodes of the last search,
                            capacity overflow flag (sticky; a search that overflowed reports failure) */

@@ -107,8 +107,9 @@ def run_trace(params, T, actions=None, policy=None, teleport=None, stop_on_done=
         else:
             a = float(actions[t])
         if teleport is not None:
-            env.drone.x, env.drone.y = teleport[t]
-            rec['tele'].append(np.array(teleport[t], dtype=np.float64))
+            pos = teleport(env, t) if callable(teleport) else teleport[t]
+            env.drone.x, env.drone.y = pos
+            rec['tele'].append(np.array(pos, dtype=np.float64))
         if mutate is not None:
             mutate(env, t)
         active_pre = np.array([tr.active for tr in env.drone.trackers[:N]], dtype=np.uint8)
@@ -328,7 +329,27 @@ def gen_short_view():
     save('closed_oxford_short_view_d50', run_trace(p, 300, policy='Oxford'))
 
 
+def gen_cfg5():
+    """BASELINE config 5's geometry through the reference itself: map_size 6400 x 6400 px = 640 x 640 cells, 640 rays
+    (rays_number = ceil(map_size[0] / 10), utils.py:570,587), 100 agents.  A handful of NoMove steps with the drone put
+    in the open, into a corner next to two border walls, and next to agents (so that rays hit them and trackers start)."""
+    p = make_params(planner='NoMove', agent_number=100, agent_radius=15, agent_max_speed=40, map_id=5,
+                    map_size=[6400, 6400], init_pos=[3200, 3200], target_list=[[6000, 6000]])
+
+    def tele(env, t):
+        if t == 0:
+            return (3200, 3200)
+        if t == 1:
+            return (17, 6381)                      # two border walls inside the view
+        a = env.agents[7 if t == 2 else 42].position
+        return (int(a[0]) + (10 if t == 2 else -20), int(a[1]) - (45 if t == 2 else 50))   # yaw ~270 looks along +y: the agent is in the cone
+    acts = [0.5, -1.0, 0.25, 1.0, 0.0]
+    save('nomove_cfg5_640', run_trace(p, len(acts), actions=acts, teleport=tele, stop_on_done=False))
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == 'cfg5':
+        return gen_cfg5()
     if len(sys.argv) > 1 and sys.argv[1] == 'short_view':
         return gen_short_view()
     if len(sys.argv) > 1 and sys.argv[1] == 'live':

@@ -115,7 +115,8 @@ class Replay:
 TRACES_NOMOVE = ['nomove_n10_const', 'nomove_n10_rand_map0', 'nomove_n10_rand_map2', 'nomove_n10_rand_map3',
                  'nomove_n10_rand_map7', 'nomove_teleport_structured', 'surv_pinned_360', 'nomove_obstacle_map',
                  'nomove_shaped_map', 'nomove_random_map_n172', 'nomove_pillars_randr', 'nomove_slow_agents',
-                 'nomove_big_map', 'freezing_nomove', 'nomove_short_view_d40']
+                 'nomove_big_map', 'freezing_nomove', 'nomove_short_view_d40',
+                 'nomove_cfg5_640']   # BASELINE config 5's geometry: 640 x 640 cells, 640 rays, 100 agents
 TRACES_PLANNED = ['readme_oxford_primitive', 'lookahead_primitive_n30_map0', 'lookahead_primitive_n30_map3',
                   'deadlock_primitive']
 TRACES_CLOSED = ['closed_oxford_n20_map0', 'closed_oxford_n20_map5', 'closed_oxford_pillars_map2', 'closed_oxford_pillars_map6',

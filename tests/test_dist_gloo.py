@@ -117,3 +117,31 @@ def test_two_shards_equal_one_process(pkg, oracle):
     want = ref.episode_stats().numpy()
     assert np.array_equal(got[0][0], want) and np.array_equal(got[1][0], want)      # every rank holds the full table
     assert np.array_equal(np.concatenate([got[0][1], got[1][1]]), ref.state.drone.numpy())
+
+
+def test_bench_two_rank_dry_run():
+    """bench.py itself, 2 ranks over gloo on the CPU (tests/bench_dry_rank.py puts the oracle behind the package's
+    backend): the launch contract of the driver (torch.distributed.run, RANK / WORLD_SIZE from the env, ONE JSON line
+    from rank 0), shards by rank, the max-over-ranks clock, the all_gather of episode statistics."""
+    import json
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(ROOT, 'tests', 'bench_dry_rank.py'), '--gpus', '2', '--steps', '6',
+           '--warmup', '2', '--prologue', '4', '--envs', '5', '--workers', '0', '--dist-backend', 'gloo', '--single-device',
+           '--leg', 'closed', '--no-cpu-baseline']
+    env = dict(os.environ, OMP_NUM_THREADS='1')
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, out.stdout
+    j = json.loads(lines[0])
+    assert j['n_gpus'] == 2 and j['n_ranks_seen'] == 2 and j['steps'] == 6 and j['warmup'] == 2 and j['scaling'] == 'weak'
+    assert j['episode_stats']['envs'] == 10 and j['gather_ms'] is not None and j['value'] > 0
+    assert abs(j['value'] - 2 * 5 * 6 / (j['ms_per_step'] * 6e-3)) < 1e-6 * j['value']
+    assert j['roofline']['traffic'] is None and 'no PMC pass' in j['roofline']['traffic_source']     # 5 envs: no such profile
+    assert j['config']['timed_window']['searches_per_env_per_step'] >= 0

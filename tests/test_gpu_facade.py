@@ -12,7 +12,12 @@ def test_readme_config_on_device(pkg, hip):
 
 
 def test_lookahead_primitive_on_device(pkg, hip):
-    run_closed_loop(pkg, hip, 'lookahead_primitive_n30_map3', 'LookAhead')
+    run_closed_loop(pkg, hip, 'lookahead_primitive_n30_map3', None)    # recorded gaze actions, device planner
+
+
+def test_train_py_shaped_params_on_device(pkg, hip):
+    from test_env_facade_cpu import test_train_py_shaped_params
+    test_train_py_shaped_params(pkg, hip)
 
 
 def test_default_backend_is_hip(pkg):

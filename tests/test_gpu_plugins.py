@@ -198,6 +198,46 @@ def test_replicas_stay_identical_at_65536_envs(pkg, hip):
     assert torch.equal(env.plugins.t['traj_hdr'][:K], small.plugins.t['traj_hdr'])
 
 
+@pytest.mark.parametrize('label,B,K,kw', [
+    ('config3', 65536, 64, dict(agent_number=50, agent_radius=10, agent_max_speed=40, static_map='maps/random_map_0.npy')),
+    ('config4_shard', 32768, 128, dict(agent_number=10, agent_radius=15, agent_max_speed=20, static_map='maps/obstacle_map.npy')),
+])
+def test_baseline_configs_closed_loop_at_full_size(pkg, hip, label, B, K, kw):
+    """BASELINE configs 3 (65536 envs x 172 agents) and 4 (one GPU's shard: 32768 envs x 24 agents) with Oxford + Primitive on
+    the device, at full size: K seeded worlds tiled over the batch, 60 closed-loop steps with auto reset; every env equals
+    the first replica of its world, and the first replicas equal a K-env run (which the oracle checks at small sizes)."""
+    from drone2d_amd import vec_env, host_init
+    p = pkg.Params(planner='Primitive', gaze_method='Oxford', drone_max_speed=40, map_id=1, **kw)
+    worlds = [host_init.init_world(pkg.with_defaults(_with_map(p, 1 + i))) for i in range(K)]
+    env = vec_env.VecDrone2DEnv(p, B, backend=hip, planner='Primitive', device_plugins=True, gaze='Oxford',
+                                worlds=[worlds[i % K] for i in range(B)])
+    small = vec_env.VecDrone2DEnv(p, K, backend=hip, planner='Primitive', device_plugins=True, gaze='Oxford', worlds=worlds)
+    for _ in range(2):
+        env.closed_loop(30, auto_reset=True)
+        small.closed_loop(30, auto_reset=True)
+    env.sync()
+    for name in ('drone', 'counters', 'dmap', 'gt', 'kf', 'agents', 'active', 'flags', 'action', 'wp', 'hit'):
+        t = env.state.t[name]
+        assert bool((t.view(B // K, K, *t.shape[1:]) == small.state.t[name].unsqueeze(0)).all()), f'{label}: {name}'
+    for name in ('traj_hdr', 'seen_step', 'trk_radius', 'trk_prev'):
+        t = env.plugins.t[name]
+        assert bool((t.view(B // K, K, *t.shape[1:]) == small.plugins.t[name].unsqueeze(0)).all()), f'{label}: {name}'
+    assert int(env.plugins.t['plan_stat'][:, 3].sum()) == 0 and env.N == worlds[0]['N']
+
+
+@pytest.mark.parametrize('label,kw', [
+    ('config3', dict(agent_number=50, agent_radius=10, agent_max_speed=40, static_map='maps/random_map_0.npy')),
+    ('config4', dict(agent_number=10, agent_radius=15, agent_max_speed=20, static_map='maps/obstacle_map.npy')),
+])
+def test_baseline_configs_closed_loop_vs_oracle(pkg, hip, oracle, label, kw):
+    """The same two configurations against the oracle: 6 seeded worlds, 80 closed-loop steps with auto reset, every field."""
+    dev, ref = _pair(pkg, hip, oracle, 6, drone_max_speed=40, map_id=1, **kw)
+    for _ in range(2):
+        dev.closed_loop(40, auto_reset=True)
+        ref.closed_loop(40, auto_reset=True)
+        _assert_same(dev, ref, label)
+
+
 def _with_map(p, map_id):
     import copy
     q = copy.copy(p)

@@ -146,6 +146,77 @@ def test_baseline_config_sizes(pkg, hip, label, B, kw):
     assert env.N == w['N'] and int(prev.sum()) > 0
 
 
+CFG5 = dict(agent_number=100, agent_radius=15, agent_max_speed=40, map_size=[6400, 6400], init_pos=[3200, 3200],
+            target_list=[[6000, 6000]])
+
+
+def _cfg5_worlds(pkg, n):
+    from drone2d_amd import host_init
+    return [host_init.init_world(pkg.with_defaults(pkg.Params(planner='NoMove', map_id=5 + i, **CFG5))) for i in range(n)]
+
+
+def _cfg5_poses(worlds, t):
+    """Drone positions of step t for the 4 worlds: open field, a corner (two border walls in view, static collision),
+    and next to an agent of the env's own world (rays hit it, a tracker starts)."""
+    from drone2d_amd import _abi as A
+    out = []
+    for i, w in enumerate(worlds):
+        k = (7 * i + 3 * t) % w['N']
+        ax, ay = float(w['agents'][A.A_PX, k]), float(w['agents'][A.A_PY, k])
+        out.append([[3200., 3200.], [17., 6381.], [int(ax) + 10., int(ay) - 45.], [6383., 12.]][(i + t) % 4])
+    return torch.tensor(out, dtype=torch.float64)
+
+
+def test_config5_geometry_vs_oracle(pkg, hip, oracle):
+    """BASELINE config 5's geometry (640 x 640 cells, 640 rays = 10 lane passes per env, 100 agents; the generic kernel
+    instantiation, no LDS coverage bitmap, 400 KB grids per env): 4 worlds x 6 steps, device == oracle in every field.
+    The oracle itself replays the reference's own trace at this geometry (golden `nomove_cfg5_640`)."""
+    from drone2d_amd import vec_env
+    worlds = _cfg5_worlds(pkg, 4)
+    p = pkg.Params(planner='NoMove', map_id=5, **CFG5)
+    ref = vec_env.VecDrone2DEnv(p, 4, backend=oracle, worlds=worlds)
+    dev = vec_env.VecDrone2DEnv(p, 4, backend=hip, worlds=worlds)
+    assert dev.cfg.R == 640 and dev.cfg.W == 640 and dev.cfg.N == 100
+    rng = np.random.RandomState(5)
+    for t in range(6):
+        a = rng.uniform(-1, 1, 4)
+        if t in (1, 2, 4):
+            xy = _cfg5_poses(worlds, t)
+            dev.state.drone[:, :2] = xy.to(dev.device)
+            ref.state.drone[:, :2] = xy
+        dev.step(a)
+        ref.step(a)
+        dev.sync()
+        for name in FIELDS:
+            assert torch.equal(dev.state.t[name].cpu(), ref.state.t[name]), f'config 5: {name} at step {t + 1}'
+    assert int(ref.state.hit.sum()) > 0 and int((ref.state.flags[:, 0] == 1).sum()) > 0    # rays hit agents, a wall collision
+
+
+def test_config5_replicas_at_shard_scale(pkg, hip):
+    """Config 5 at 4096 envs (6.7 GB of grids with the reset snapshot; one GPU's shard of the 262144-env job is 8x
+    that and takes the same code path): every env equals the 4-env run of its world, bit for bit."""
+    from drone2d_amd import vec_env
+    worlds = _cfg5_worlds(pkg, 4)
+    p = pkg.Params(planner='NoMove', map_id=5, **CFG5)
+    B = 4096
+    big = vec_env.VecDrone2DEnv(p, B, backend=hip, worlds=[worlds[i % 4] for i in range(B)])
+    small = vec_env.VecDrone2DEnv(p, 4, backend=hip, worlds=worlds)
+    rng = np.random.RandomState(6)
+    for t in range(5):
+        a4 = torch.from_numpy(rng.uniform(-1, 1, 4))
+        if t in (1, 3):
+            xy = _cfg5_poses(worlds, t).to(big.device)
+            big.state.drone[:, :2] = xy.repeat(B // 4, 1)
+            small.state.drone[:, :2] = xy
+        big.step(a4.repeat(B // 4))
+        small.step(a4)
+    big.sync()
+    for name in FIELDS:
+        x = big.state.t[name]
+        assert bool((x.view(B // 4, 4, *x.shape[1:]) == small.state.t[name].unsqueeze(0)).all()), name
+    assert int(small.state.hit.sum()) > 0
+
+
 def test_full_size_properties(pkg, hip):
     """BASELINE config 2 size (4096 envs x 10 agents): size-independent properties on the device alone:
     (i) a batch of identical worlds stays identical, (ii) wall cells of gt never change, explored cells only

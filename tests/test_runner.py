@@ -22,7 +22,8 @@ def _rows(backend, device, which):
 
 
 def test_csv_rows_match_reference_cpu(pkg, oracle):
-    _rows(oracle, 'cpu', range(3))
+    _rows(oracle, 'cpu', [0, 2])      # row 1 is a LookAhead episode: the reference's own class drives it in
+    #                                   test_dropin_reference_plugins.py (build container)
 
 
 @pytest.mark.gpu

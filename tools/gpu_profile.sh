@@ -1,21 +1,23 @@
 #!/bin/bash
-# Runs on the GPU box (via gpurun): kernel-trace profile + PMC passes of the bench workload.
-# Outputs land in gpurun_out/<tag>/ ; copy the summaries into profiles/ afterwards.
+# Runs on the GPU box (via gpurun): rocprofv3 kernel trace + PMC passes of the three legs of bench.py, each leg in its own
+# invocation (--leg closed | step | raycast) so that every k_stages row of a trace belongs to one leg.
+# Counters are collected in their own runs (never together with a trace).  Outputs land in gpurun_out/<tag>/ ; copy
+# summary.txt, kernel_stats_*.csv and pmc_latest.json into profiles/ afterwards.
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG; rm -rf "$OUT"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 600 --warmup 300 --no-cpu-baseline --workers 0 ${BENCH_ARGS:-}"
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/ktrace" -- python3 "$ROOT/bench.py" $ARGS > "$OUT/ktrace.log" 2>&1
-for ctr in FETCH_SIZE WRITE_SIZE; do
-  timeout 600 rocprofv3 --pmc $ctr --output-format csv -d "$OUT/pmc_$ctr" -- python3 "$ROOT/bench.py" $ARGS > "$OUT/pmc_$ctr.log" 2>&1
+LEGS=${LEGS:-closed step raycast}
+for leg in $LEGS; do
+  ARGS="--steps 600 --warmup 300 --no-cpu-baseline --workers 0 --leg $leg ${BENCH_ARGS:-}"
+  timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/$leg/ktrace" -- python3 "$ROOT/bench.py" $ARGS > "$OUT/$leg.ktrace.log" 2>&1 || { echo "ktrace $leg failed"; tail -5 "$OUT/$leg.ktrace.log"; exit 1; }
+  for ctr in FETCH_SIZE WRITE_SIZE; do
+    timeout -k 10 600 rocprofv3 --pmc $ctr --output-format csv -d "$OUT/$leg/pmc_$ctr" -- python3 "$ROOT/bench.py" $ARGS > "$OUT/$leg.pmc_$ctr.log" 2>&1 || { echo "pmc $ctr $leg failed"; exit 1; }
+  done
+  timeout -k 10 600 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d "$OUT/$leg/pmc_sq" -- python3 "$ROOT/bench.py" $ARGS > "$OUT/$leg.pmc_sq.log" 2>&1 || { echo "pmc sq $leg failed"; exit 1; }
+  echo "leg $leg done"
 done
-timeout 600 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d "$OUT/pmc_sq" -- python3 "$ROOT/bench.py" $ARGS > "$OUT/pmc_sq.log" 2>&1
-python3 "$ROOT/tools/summarize_profile.py" "$OUT" > "$OUT/summary.txt" 2>&1
-cat "$OUT/summary.txt"
-# instruction cache / issue counters of the persistent kernel (own pass; tolerated to fail on a pool without them)
-timeout 600 rocprofv3 --pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQ_INSTS_SALU SQ_WAIT_INST_ANY SQ_BUSY_CYCLES --output-format csv -d "$OUT/pmc_sq2" -- python3 "$ROOT/bench.py" $ARGS > "$OUT/pmc_sq2.log" 2>&1
-python3 "$ROOT/tools/summarize_profile.py" "$OUT" > "$OUT/summary.txt" 2>&1
-tail -40 "$OUT/summary.txt"
+python3 "$ROOT/tools/summarize_profile.py" "$OUT" "${BENCH_ARGS:-}" > "$OUT/summary.txt" 2>&1
+tail -60 "$OUT/summary.txt"
