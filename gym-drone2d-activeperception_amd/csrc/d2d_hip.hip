@@ -147,12 +147,14 @@ struct Geom {
   int klo;    // samples 0..klo are < depth from the drone whatever the slope (k * ss * sqrt(2) < depth)
   int bmw;    // dwords of the per-env cell bitmap kept in LDS (0: grid too large, loop over agents instead)
   int kf_lds; // tracker state staged in LDS (fits the 64 KB workgroup budget)
+  int full;   // both grids staged WHOLE in LDS (the specialised 50 x 50 geometry): gtw / dmt are the full copies, no tiles, no bitmap
   int wave_bytes;
 };
 
 // `wpb`: waves (envs) per workgroup; the LDS budget of a workgroup is 64 KB
-__host__ __device__ inline Geom make_geom(const d2d_cfg &c, int wpb, int ncap_fixed = 0) {
+__host__ __device__ inline Geom make_geom(const d2d_cfg &c, int wpb, int ncap_fixed = 0, bool full = false) {
   Geom g;
+  g.full = full ? 1 : 0;
   g.ncap = (c.N + 3) & ~3;
   if (g.ncap < 4) g.ncap = 4;
   if (ncap_fixed) g.ncap = ncap_fixed;
@@ -167,6 +169,11 @@ __host__ __device__ inline Geom make_geom(const d2d_cfg &c, int wpb, int ncap_fi
   if (g.klo < -1) g.klo = -1;
   g.bmw = (c.W * c.H + 31) / 32;
   if (g.bmw > 2048) g.bmw = 0;  // 8 KB per wave at most (256 x 256 cells)
+  if (full) {  // whole grids: W * H bytes each (rounded to 16), the dynamic-grid coverage marks live in the gt copy itself
+    g.wdw = ((c.W * c.H + 15) & ~15) / 4;
+    g.ldw = g.wdw;
+    g.bmw = 0;
+  }
   const int base = 64 * g.ncap + 32 * g.ncap + 4 * g.bmw + 4 * g.wdw + 4 * g.ldw + 2 * g.ncap;
   g.kf_lds = (c.kf_enabled && ((base + 160 * g.ncap + 15) & ~15) * wpb <= 64 * 1024) ? 1 : 0;
   g.wave_bytes = (base + (g.kf_lds ? 160 * g.ncap : 0) + 15) & ~15;
@@ -598,7 +605,8 @@ __device__ __forceinline__ Ray ray_setup(const d2d_cfg &c, const LdsView &L, int
 // k > klo (earlier ones are nearer than `depth` for any slope).
 // GENERAL: some ray of the wave has more than one candidate (or the env more than 32): the per-sample LDS
 // candidate loops are compiled in.  The common instantiation tests only the register-held first candidate.
-template <bool GENERAL>
+// FULL: L.gtw / L.dmt are copies of the WHOLE grids (Geom.full), indexed by the cell itself -- no window / crop arithmetic.
+template <bool GENERAL, bool FULL>
 __device__ __forceinline__ void ray_march(const d2d_cfg &c, const Geom &g, const LdsView &L, const Ray &ry, bool active,
                                           int ncand, double x0, double y0, const Tile &wt, const Tile &ct, bool patch,
                                           unsigned char *__restrict__ dm) {
@@ -653,19 +661,31 @@ __device__ __forceinline__ void ray_march(const d2d_cfg &c, const Geom &g, const
     // garbage position just reads some tile byte that is then ignored); it must not become a select between
     // an LDS and a global pointer (flat load + vmcnt(0) wait per sample).
     const int ci = cell(x), cj = cell(y);
-    const int wr = min(max(ci - wt.i0, 0), wt.rows - 1), wq = min(max(cj - wt.j0, 0), wt.cols - 1);
-    const unsigned char wall = gtw[wt.byte_index(wr, wq)];
+    int gi = 0;
+    unsigned char wall;
+    if constexpr (FULL) {
+      gi = alive ? ci * H + cj : 0;  // a live sample lies inside the map (0 < x < W_px): the index is the cell's own
+      wall = gtw[gi];
+    } else {
+      const int wr = min(max(ci - wt.i0, 0), wt.rows - 1), wq = min(max(cj - wt.j0, 0), wt.cols - 1);
+      wall = gtw[wt.byte_index(wr, wq)];
+    }
     bool far = false;
     if (FAR) far = ((x - x0) * (x - x0) + (y - y0) * (y - y0) >= depth2);
     const bool stop = (wall == D2D_OCCUPIED) || far;
     const bool write = alive && !any && (!stop || wall == D2D_OCCUPIED);
     if (write) {
       const unsigned char v = stop ? (unsigned char)D2D_OCCUPIED : (unsigned char)D2D_UNOCCUPIED;
+      if constexpr (FULL) {
+        dm[gi] = v;
+        if (patch) dmt[gi] = v;  // the copy the observation crop is cut from
+      } else {
 #ifndef D2D_ABL_NOSTORE
-      dm[ci * H + cj] = v;
+        dm[ci * H + cj] = v;
 #endif
-      const unsigned int pr = (unsigned int)(ci - ct.i0), pq = (unsigned int)(cj - ct.j0);  // observation tile in step
-      if (patch && pr < (unsigned int)ct.rows && pq < (unsigned int)ct.cols) dmt[pr * ct.cols + pq] = v;
+        const unsigned int pr = (unsigned int)(ci - ct.i0), pq = (unsigned int)(cj - ct.j0);  // observation tile in step
+        if (patch && pr < (unsigned int)ct.rows && pq < (unsigned int)ct.cols) dmt[pr * ct.cols + pq] = v;
+      }
     }
     alive = alive && !any && !stop;
     x = x + ry.xs;
@@ -814,6 +834,139 @@ __device__ __forceinline__ void dyn_apply(const d2d_cfg &c, const d2d_state &s, 
   if (pcx != ncx) prev[3 * k] = ncx;
   if (pcy != ncy) prev[3 * k + 1] = ncy;
   if (pu != nu) prev[3 * k + 2] = nu;
+}
+
+
+// ---- whole-grid staging (Geom.full: the specialised 50 x 50 geometry) ----
+// A grid of one env (W * H bytes, a multiple of 4, dword aligned because every env's offset is) -> LDS by DMA, four bytes
+// per lane per instruction (the env's block is not 16-byte aligned in general); no VGPRs, the caller's vmcnt(0) covers it.
+__device__ __forceinline__ void grid_stage(const unsigned char *__restrict__ src, unsigned int *dst, int nbytes, int lane) {
+  const int nd = nbytes >> 2;
+  for (int base = 0; base < nd; base += WAVE) {
+    const int idx = base + lane;
+    if (idx < nd)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + (size_t)idx * 4),
+                                       (__attribute__((address_space(3))) void *)((char *)dst + (size_t)base * 4), 4, 0, 0);
+  }
+}
+
+// utils.py:527-540 on the LDS copy of the ground truth, lane = agent.  Same order-independent rule as dyn_apply (final
+// value of a cell = static ? unchanged : covered by some new block ? DYNAMIC : was DYNAMIC ? UNOCCUPIED : unchanged), with the
+// coverage kept IN the copy: every agent first ORs a mark (bit 7) into the cells of its new block, then a previous cell
+// that holds DYNAMIC without a mark is cleared and a new cell that is neither static nor DYNAMIC is set -- in global memory
+// only (the copy is scratch from here on: nothing reads it after this stage).
+__device__ __forceinline__ void dyn_full(const d2d_cfg &c, const d2d_state &s, int e, int lane, const LdsView &L,
+                                         unsigned char *__restrict__ gt) {
+  const int N = c.N, W = c.W, H = c.H;
+  unsigned char *g8 = (unsigned char *)L.gtw;
+  int *prev = s.dyn_prev + (size_t)e * N * 3;
+  bool small = true;
+  for (int k = lane; k < N; k += WAVE) small = small && (L.pu[k] <= 1 && L.nu[k] <= 1);
+  if (__all(small)) {
+    // blocks of at most 3 x 3 cells: fixed trip counts, the cells of a block at constant offsets of one index
+    for (int k0 = 0; k0 < N; k0 += WAVE) {
+      const int k = k0 + lane, kc = min(k, N - 1);
+      const bool on = k < N;
+      const int ncx = L.ncx[kc], ncy = L.ncy[kc], nu = L.nu[kc];
+      const unsigned int nval = on ? block_valid9(ncx, ncy, nu, W, H) : 0u;
+#pragma unroll
+      for (int q = 0; q < 9; ++q) {
+        const int di = q / 3 - 1, dj = q % 3 - 1;
+        if ((nval >> q) & 1u) {
+          const int idx = (ncx + di) * H + (ncy + dj);
+          g8[idx] = g8[idx] | 0x80;
+        }
+      }
+    }
+    wave_sync_lds();
+    for (int k0 = 0; k0 < N; k0 += WAVE) {
+      const int k = k0 + lane, kc = min(k, N - 1);
+      const bool on = k < N;
+      const int pcx = L.pcx[kc], pcy = L.pcy[kc], pu = L.pu[kc], ncx = L.ncx[kc], ncy = L.ncy[kc], nu = L.nu[kc];
+      const unsigned int pval = on ? block_valid9(pcx, pcy, pu, W, H) : 0u, nval = on ? block_valid9(ncx, ncy, nu, W, H) : 0u;
+      unsigned char pv[9], nv[9];
+#pragma unroll
+      for (int q = 0; q < 9; ++q) {  // clamped (always valid) addresses, all reads in flight together
+        const int di = q / 3 - 1, dj = q % 3 - 1;
+        pv[q] = g8[min(max(pcx + di, 0), W - 1) * H + min(max(pcy + dj, 0), H - 1)];
+        nv[q] = g8[min(max(ncx + di, 0), W - 1) * H + min(max(ncy + dj, 0), H - 1)];
+      }
+      unsigned int pclr = 0, nset = 0;
+#pragma unroll
+      for (int q = 0; q < 9; ++q) {
+        pclr |= (pv[q] == D2D_DYNAMIC) ? (1u << q) : 0u;  // DYNAMIC and unmarked
+        const unsigned char o = nv[q] & 0x7f;
+        nset |= (o != D2D_OCCUPIED && o != D2D_DYNAMIC) ? (1u << q) : 0u;
+      }
+      unsigned int m = pclr & pval;
+      while (m) {
+        const int q = __ffs((int)m) - 1;
+        m &= m - 1;
+        gt[(pcx + q / 3 - 1) * H + (pcy + q % 3 - 1)] = D2D_UNOCCUPIED;
+      }
+      m = nset & nval;
+      while (m) {
+        const int q = __ffs((int)m) - 1;
+        m &= m - 1;
+        gt[(ncx + q / 3 - 1) * H + (ncy + q % 3 - 1)] = D2D_DYNAMIC;
+      }
+      if (on) {
+        if (pcx != ncx) prev[3 * k] = ncx;
+        if (pcy != ncy) prev[3 * k + 1] = ncy;
+        if (pu != nu) prev[3 * k + 2] = nu;
+      }
+    }
+    return;
+  }
+  for (int k = lane; k < N; k += WAVE) {  // any block size: plain loops
+    const int ncx = L.ncx[k], ncy = L.ncy[k], nu = L.nu[k];
+    const int i1 = min(ncx + nu + 1, W), j1 = min(ncy + nu + 1, H);
+    for (int i = max(ncx - nu, 0); i < i1; ++i)
+      for (int j = max(ncy - nu, 0); j < j1; ++j) g8[i * H + j] = g8[i * H + j] | 0x80;
+  }
+  wave_sync_lds();
+  for (int k = lane; k < N; k += WAVE) {
+    const int pcx = L.pcx[k], pcy = L.pcy[k], pu = L.pu[k], ncx = L.ncx[k], ncy = L.ncy[k], nu = L.nu[k];
+    const int i1 = min(pcx + pu + 1, W), j1 = min(pcy + pu + 1, H);
+    for (int i = max(pcx - pu, 0); i < i1; ++i)
+      for (int j = max(pcy - pu, 0); j < j1; ++j)
+        if (g8[i * H + j] == D2D_DYNAMIC) gt[i * H + j] = D2D_UNOCCUPIED;
+    const int i3 = min(ncx + nu + 1, W), j3 = min(ncy + nu + 1, H);
+    for (int i = max(ncx - nu, 0); i < i3; ++i)
+      for (int j = max(ncy - nu, 0); j < j3; ++j) {
+        const unsigned char o = g8[i * H + j] & 0x7f;
+        if (o != D2D_OCCUPIED && o != D2D_DYNAMIC) gt[i * H + j] = D2D_DYNAMIC;
+      }
+    if (pcx != ncx) prev[3 * k] = ncx;
+    if (pcy != ncy) prev[3 * k + 1] = ncy;
+    if (pu != nu) prev[3 * k + 2] = nu;
+  }
+}
+
+// utils.py:780-784 + envs/drone_v2.py:251-255 from the LDS copy of the whole explored map (which the rays patched): the
+// L x L crop around cell (ci, cj), zero outside the map.  Two crop rows per pass (lanes 0-31 / 32-63 = the first 32 columns of
+// rows 2t / 2t + 1), further columns by lane = row: indices advance by constants, no division.
+__device__ __forceinline__ void obs_full(const d2d_cfg &c, const d2d_state &s, int e, int lane, const LdsView &L, int ci, int cj,
+                                         const EnvRegs &r) {
+  const int W = c.W, H = c.H, Lm = c.L, edge = (c.L - 1) / 2;
+  const unsigned char *d8 = (const unsigned char *)L.dmt;
+  unsigned char *__restrict__ ob = s.obs_local + (size_t)e * Lm * Lm;
+  const int i0 = ci - edge, j0 = cj - edge;
+  const int half = lane >> 5, col = lane & 31;
+  const int j = j0 + col;
+  const bool jok = col < Lm && j >= 0 && j < H;
+  const int jc = min(max(j, 0), H - 1);
+  for (int t = 0; 2 * t < Lm; ++t) {
+    const int rr = 2 * t + half, i = i0 + rr;
+    const unsigned char v = d8[min(max(i, 0), W - 1) * H + jc];
+    if (rr < Lm && col < Lm) ob[rr * Lm + col] = (jok && i >= 0 && i < W) ? v : (unsigned char)0;
+  }
+  for (int c0 = 32; c0 < Lm; ++c0) {  // column c0 of every row, lane = row (Lm <= 64 rows checked by the caller)
+    const int i = i0 + lane, jj = j0 + c0;
+    const unsigned char v = d8[min(max(i, 0), W - 1) * H + min(max(jj, 0), H - 1)];
+    if (lane < Lm) ob[lane * Lm + c0] = (i >= 0 && i < W && jj >= 0 && jj < H) ? v : (unsigned char)0;
+  }
+  if (lane == 0) s.obs_yaw[e] = (float)r.yaw;
 }
 
 // ---- Kalman trackers, utils.py:172-275; lane = tracker slot ----
@@ -1029,6 +1182,9 @@ __device__ __forceinline__ void store_regs(const d2d_state &s, int e, const EnvR
 //    raycast keeps using the pose from before it (x0, y0, yaw0);
 //  * all loads addressed by batch-1 data (window, crop, grid cells, probes) are issued together, and the
 //    per-ray tan / candidate work runs while they are in flight.
+// FULL (Geom.full, the specialised 50 x 50 geometry): both grids are staged WHOLE in LDS by DMA in batch 1 -- there is no
+// batch 2 at all: rays, collision probes, the dynamic-grid update and the observation crop read the copies.
+template <bool FULL>
 __device__ __forceinline__ void run_env(const d2d_cfg &c, const d2d_state &s, int e, int lane, uint32_t stages,
                                         const Geom &g, const LdsView &L, double action, EnvRegs &r) {
   const int N = c.N, W = c.W, H = c.H;
@@ -1039,6 +1195,10 @@ __device__ __forceinline__ void run_env(const d2d_cfg &c, const d2d_state &s, in
   unsigned char *__restrict__ dm = s.dmap + (size_t)e * W * H;
 
   // ---------------- batch 1 ----------------
+  if constexpr (FULL) {
+    if (do_ray || do_dyn || do_col) grid_stage(gt, L.gtw, W * H, lane);
+    if (do_obs) grid_stage(dm, L.dmt, W * H, lane);
+  }
   StepIn in;
   load_inputs(c, s, e, action, do_ctl, in);
   D2D_STAMP(1);
@@ -1056,37 +1216,40 @@ __device__ __forceinline__ void run_env(const d2d_cfg &c, const d2d_state &s, in
   }
   D2D_STAMP(3);
 
-  // ---------------- batch 2 (addresses from batch-1 data) ----------------
+  // ---------------- batch 2 (addresses from batch-1 data; tile path only) ----------------
   const int ocx = cell_fast(x0, c.scale, inv_scale), ocy = cell_fast(y0, c.scale, inv_scale);
+  const int ncx_d = cell_fast(r.x, c.scale, inv_scale), ncy_d = cell_fast(r.y, c.scale, inv_scale);  // the drone's cell after control
   const int edge = (c.L - 1) / 2;
   const Tile wt = make_tile(ocx - g.reach, ocy - g.reach, g.ws, g.ws);
-  const Tile ct = make_tile(cell_fast(r.x, c.scale, inv_scale) - edge, cell_fast(r.y, c.scale, inv_scale) - edge, c.L, c.L);
-  if (do_ray && do_obs && wt.cols <= 32 && wt.rows <= 24 && ct.cols <= 33 && ct.rows <= 34) {
-    // default geometry (23 x 23 window, 33 x 33 crop): lanes map to (row parity, column), so a cell costs an
-    // add and a compare instead of a division; all loads of both tiles are in flight before the first LDS write
-    tile_rows2(wt, (unsigned char *)L.gtw, gt, W, H, lane, (unsigned char)D2D_OCCUPIED,
-               ct, (unsigned char *)L.dmt, dm, (unsigned char)0);
-  } else {
-    if (do_ray) tile_load<9>(wt, (unsigned char *)L.gtw, gt, W, H, lane, (unsigned char)D2D_OCCUPIED);
-    if (do_obs) tile_load<9>(ct, (unsigned char *)L.dmt, dm, W, H, lane, (unsigned char)0);
-  }
+  const Tile ct = make_tile(ncx_d - edge, ncy_d - edge, c.L, c.L);
   bool probe_wall = false;
-  if (do_col && lane < 5) {  // utils.py:766-771: static cells never change, so the probes can be read now
-    const double R = c.drone_radius;
-    const double ox = (lane == 0) ? -R : (lane == 2 ? R : 0.0);
-    const double oy = (lane == 3) ? -R : (lane == 4 ? R : 0.0);
-    const double qx = r.x + ox, qy = r.y + oy;
-    const bool oob = (qx >= c.W_px || qx < 0.0 || qy >= c.H_px || qy < 0.0);
-    const int pi = min(max(cell_fast(qx, c.scale, inv_scale), 0), W - 1), pj = min(max(cell_fast(qy, c.scale, inv_scale), 0), H - 1);
-    probe_wall = oob || gt[pi * H + pj] == D2D_OCCUPIED;
-  }
   const bool dyn_fast = do_dyn && N <= WAVE;
-  if (do_dyn) dyn_bitmap(c, lane, g, L);
   DynCells dc;
   dc.pclr = dc.nfree = 0;
-  if (dyn_fast && lane < N) dyn_load(c, gt, lane, L, dc);
+  if constexpr (!FULL) {
+    if (do_ray && do_obs && wt.cols <= 32 && wt.rows <= 24 && ct.cols <= 33 && ct.rows <= 34) {
+      // default geometry (23 x 23 window, 33 x 33 crop): lanes map to (row parity, column), so a cell costs an
+      // add and a compare instead of a division; all loads of both tiles are in flight before the first LDS write
+      tile_rows2(wt, (unsigned char *)L.gtw, gt, W, H, lane, (unsigned char)D2D_OCCUPIED,
+                 ct, (unsigned char *)L.dmt, dm, (unsigned char)0);
+    } else {
+      if (do_ray) tile_load<9>(wt, (unsigned char *)L.gtw, gt, W, H, lane, (unsigned char)D2D_OCCUPIED);
+      if (do_obs) tile_load<9>(ct, (unsigned char *)L.dmt, dm, W, H, lane, (unsigned char)0);
+    }
+    if (do_col && lane < 5) {  // utils.py:766-771: static cells never change, so the probes can be read now
+      const double R = c.drone_radius;
+      const double ox = (lane == 0) ? -R : (lane == 2 ? R : 0.0);
+      const double oy = (lane == 3) ? -R : (lane == 4 ? R : 0.0);
+      const double qx = r.x + ox, qy = r.y + oy;
+      const bool oob = (qx >= c.W_px || qx < 0.0 || qy >= c.H_px || qy < 0.0);
+      const int pi = min(max(cell_fast(qx, c.scale, inv_scale), 0), W - 1), pj = min(max(cell_fast(qy, c.scale, inv_scale), 0), H - 1);
+      probe_wall = oob || gt[pi * H + pj] == D2D_OCCUPIED;
+    }
+    if (do_dyn) dyn_bitmap(c, lane, g, L);
+    if (dyn_fast && lane < N) dyn_load(c, gt, lane, L, dc);
+  }
 
-  // ---------------- raycast: setup while batch 2 is in flight ----------------
+  // ---------------- raycast: setup while the loads are in flight ----------------
   int ncand = 0;
   if (do_ray) {
     ncand = ray_cull(c, lane, L, x0, y0);
@@ -1096,15 +1259,30 @@ __device__ __forceinline__ void run_env(const d2d_cfg &c, const d2d_state &s, in
   }
   wave_sync_lds();
   D2D_STAMP(4);
+  // FULL: everything that reads the staged copies waits here once (the tracker DMA is covered too)
+  auto landed = [&]() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    wave_sync_lds();
+    if constexpr (FULL) {
+      if (do_col && lane < 5) {  // utils.py:766-771 from the ground-truth copy, BEFORE the dynamic-grid stage marks it
+        const double R = c.drone_radius;
+        const double ox = (lane == 0) ? -R : (lane == 2 ? R : 0.0);
+        const double oy = (lane == 3) ? -R : (lane == 4 ? R : 0.0);
+        const double qx = r.x + ox, qy = r.y + oy;
+        const bool oob = (qx >= c.W_px || qx < 0.0 || qy >= c.H_px || qy < 0.0);
+        const int pi = min(max(cell_fast(qx, c.scale, inv_scale), 0), W - 1), pj = min(max(cell_fast(qy, c.scale, inv_scale), 0), H - 1);
+        probe_wall = oob || ((const unsigned char *)L.gtw)[pi * H + pj] == D2D_OCCUPIED;
+      }
+    }
+  };
   int newly = 0;
   if (do_ray) {
     bool go = false;  // do the rays continue past sample 0?
     for (int i0 = 0; i0 < c.R; i0 += WAVE) {
       const int i = i0 + lane;
       const Ray ry = ray_setup(c, L, i, ncand, x0, y0, yaw0);
-      if (i0 == 0) {  // the tracker DMA and the tiles have to be in LDS before the first sample reads / patches them
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        wave_sync_lds();
+      if (i0 == 0) {  // the tracker DMA and the tiles / grids have to be in LDS before the first sample reads / patches them
+        landed();
         D2D_STAMP(5);
         // Sample 0 of every ray is the drone's own position (utils.py:641-642), so its outcome is shared: an
         // agent covering it stops every ray before the map is touched (:658-664), else its cell is recorded.
@@ -1119,21 +1297,26 @@ __device__ __forceinline__ void run_env(const d2d_cfg &c, const d2d_state &s, in
         }
         go = go && !__any(cover);
         if (go) {  // dist == 0 < depth^2: only a wall stops the rays here
-          const unsigned char w0 = ((const unsigned char *)L.gtw)[wt.byte_index(g.reach, g.reach)];
+          const int g0 = FULL ? ocx * H + ocy : wt.byte_index(g.reach, g.reach);  // `go`: the drone is inside the map
+          const unsigned char w0 = ((const unsigned char *)L.gtw)[g0];
           const unsigned char v0 = (w0 == D2D_OCCUPIED) ? (unsigned char)D2D_OCCUPIED : (unsigned char)D2D_UNOCCUPIED;
           if (lane == 0) {
 #ifndef D2D_ABL_NOSTORE
             dm[ocx * H + ocy] = v0;
 #endif
-            const unsigned int pr = (unsigned int)(ocx - ct.i0), pq = (unsigned int)(ocy - ct.j0);
-            if (do_obs && pr < (unsigned int)ct.rows && pq < (unsigned int)ct.cols) ((unsigned char *)L.dmt)[pr * ct.cols + pq] = v0;
+            if constexpr (FULL) {
+              if (do_obs) ((unsigned char *)L.dmt)[g0] = v0;
+            } else {
+              const unsigned int pr = (unsigned int)(ocx - ct.i0), pq = (unsigned int)(ocy - ct.j0);
+              if (do_obs && pr < (unsigned int)ct.rows && pq < (unsigned int)ct.cols) ((unsigned char *)L.dmt)[pr * ct.cols + pq] = v0;
+            }
           }
           go = (w0 != D2D_OCCUPIED);
         }
       }
       const bool general = ncand > 32 || __any((ry.cmask & (ry.cmask - 1u)) != 0u);
-      if (general) ray_march<true>(c, g, L, ry, go && i < c.R, ncand, x0, y0, wt, ct, do_obs, dm);
-      else ray_march<false>(c, g, L, ry, go && i < c.R, ncand, x0, y0, wt, ct, do_obs, dm);
+      if (general) ray_march<true, FULL>(c, g, L, ry, go && i < c.R, ncand, x0, y0, wt, ct, do_obs, dm);
+      else ray_march<false, FULL>(c, g, L, ry, go && i < c.R, ncand, x0, y0, wt, ct, do_obs, dm);
     }
     wave_sync_lds();
     D2D_STAMP(6);
@@ -1150,9 +1333,8 @@ __device__ __forceinline__ void run_env(const d2d_cfg &c, const d2d_state &s, in
     }
     if (lane == 0) s.newly[e] = newly;
     r.tracked += newly;
-  } else if (do_obs || do_trk) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
+  } else if (FULL ? (do_obs || do_trk || do_dyn || do_col) : (do_obs || do_trk)) {
+    landed();
   }
   D2D_STAMP(7);
 #ifndef D2D_ABL_NOTRK
@@ -1164,7 +1346,9 @@ __device__ __forceinline__ void run_env(const d2d_cfg &c, const d2d_state &s, in
   D2D_STAMP(8);
 #ifndef D2D_ABL_NODYN
   if (do_dyn) {
-    if (dyn_fast) {
+    if constexpr (FULL) {
+      dyn_full(c, s, e, lane, L, gt);
+    } else if (dyn_fast) {
       if (lane < N) dyn_apply<true>(c, s, e, lane, g, L, gt, dc);
     } else {
       for (int k = lane; k < N; k += WAVE) dyn_apply<false>(c, s, e, k, g, L, gt, dc);
@@ -1180,7 +1364,8 @@ __device__ __forceinline__ void run_env(const d2d_cfg &c, const d2d_state &s, in
 #ifndef D2D_ABL_NOOBS
   if (do_obs) {
     wave_sync_lds();
-    st_obs(c, s, e, lane, L, r);
+    if constexpr (FULL) obs_full(c, s, e, lane, L, ncx_d, ncy_d, r);
+    else st_obs(c, s, e, lane, L, r);
   }
 #endif
   D2D_STAMP(12);
@@ -1224,7 +1409,7 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK, D2D_MIN_WAVES) void k_stages
   const int e = blockIdx.x * wpb + wv;
   if (e >= c.B) return;
   if ((stages & D2D_ST_SKIP_DONE) && s.flags[(size_t)e * 4 + D2D_F_DONE] != 0) return;
-  const Geom g = make_geom(c, wpb, spec_ncap(SPEC));
+  const Geom g = make_geom(c, wpb, spec_ncap(SPEC), SPEC != 0);
   const LdsView L = carve(d2d_lds + (size_t)wv * g.wave_bytes, g, c.L);
   EnvRegs r;
 #ifdef D2D_STAMPS
@@ -1239,7 +1424,7 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK, D2D_MIN_WAVES) void k_stages
     r.x = pin[(size_t)e * 2];
     r.y = pin[(size_t)e * 2 + 1];
   }
-  run_env(c, s, e, lane, stages, g, L, s.action[e], r);
+  run_env<SPEC != 0>(c, s, e, lane, stages, g, L, s.action[e], r);
   if (lane == 0) {
     store_regs(s, e, r);
     if (coll_out) coll_out[e] = s.flags[(size_t)e * 4 + D2D_F_COLLISION];
@@ -1337,7 +1522,7 @@ __global__ void k_closed_args(ClosedArgs *dst, d2d_cfg c, d2d_state s, d2d_plan 
 
 template <int SPEC>
 __host__ __device__ inline int closed_wave_bytes(const d2d_cfg &c, const d2d_plan &p, int wpb) {
-  int b = make_geom(c, wpb, spec_ncap(SPEC)).wave_bytes;
+  int b = make_geom(c, wpb, spec_ncap(SPEC), SPEC != 0).wave_bytes;
   const int pb = plan_wave_bytes(c.N, p.nu, p.n_sample, c.W * c.H), gb = p.gaze == D2D_GAZE_OXFORD ? gaze_geom(c, p).wave_bytes : 0;
   b = b > pb ? b : pb;
   b = b > gb ? b : gb;
@@ -1394,11 +1579,11 @@ __device__ __attribute__((noinline)) void ph_gaze_stages(const ClosedArgs *ap, i
   gaze_env(c, a->s, a->p, a->init, a->on_done == D2D_DONE_RESET, e, lane, base);
   wave_sync_global();
   const int wpb = (SPEC == 1 || SPEC == 2) ? WAVES_PER_BLOCK : (int)(blockDim.x / WAVE);
-  const Geom g = make_geom(c, wpb, spec_ncap(SPEC));
+  const Geom g = make_geom(c, wpb, spec_ncap(SPEC), SPEC != 0);
   const LdsView L = carve(base, g, c.L);
   EnvRegs r;
   load_regs(a->s, e, r);
-  run_env(c, a->s, e, lane, STAGES, g, L, a->s.action[e], r);
+  run_env<SPEC != 0>(c, a->s, e, lane, STAGES, g, L, a->s.action[e], r);
   if (lane == 0) store_regs(a->s, e, r);
   wave_sync_global();
 }
@@ -1411,11 +1596,11 @@ __device__ __attribute__((noinline)) void ph_stages(const ClosedArgs *ap, int e_
   d2d_cfg c = a->c;
   if (SPEC != 0) spec_default_apply(c);
   const int wpb = (SPEC == 1 || SPEC == 2) ? WAVES_PER_BLOCK : (int)(blockDim.x / WAVE);
-  const Geom g = make_geom(c, wpb, spec_ncap(SPEC));
+  const Geom g = make_geom(c, wpb, spec_ncap(SPEC), SPEC != 0);
   const LdsView L = carve(base, g, c.L);
   EnvRegs r;
   load_regs(a->s, e, r);
-  run_env(c, a->s, e, lane, STAGES, g, L, a->s.action[e], r);
+  run_env<SPEC != 0>(c, a->s, e, lane, STAGES, g, L, a->s.action[e], r);
   if (lane == 0) store_regs(a->s, e, r);
   wave_sync_global();
 }
@@ -1464,11 +1649,32 @@ int fail(int code, const char *msg) {
   return code;
 }
 
-// envs per workgroup: as many waves as fit the 64 KB LDS budget (4, 2 or 1); 0 = does not fit at all
+// LDS of one workgroup.  A CU has 160 KB; occupancy (waves per CU) is what the per-wave working set allows whatever the
+// workgroup size, so workgroups stay within 64 KB (several of them per CU) -- except that a SINGLE wave whose working set
+// exceeds 64 KB (many agents, deep views, large plugin tables) gets a workgroup of its own with up to the whole 160 KB,
+// which the kernel has to opt into (hipFuncAttributeMaxDynamicSharedMemorySize).
+constexpr size_t LDS_SOFT = 64 * 1024, LDS_HARD = 160 * 1024;
+
+template <typename K>
+void lds_optin(K kernel, size_t bytes) {
+  if (bytes > LDS_SOFT) (void)hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+// does this configuration take the specialised kernels (default geometry: grids staged whole in LDS)?
+bool spec_path(const d2d_cfg &c) {
+#ifndef D2D_NO_SPEC
+  return spec_default_matches(c);
+#else
+  return false;
+#endif
+}
+
+// envs per workgroup: as many waves as fit the 64 KB budget (4, 2 or 1), one wave with up to 160 KB; 0 = does not fit at all
 int pick_wpb(const d2d_cfg &c) {
+  const bool full = spec_path(c);
   for (int wpb = WAVES_PER_BLOCK; wpb >= 1; wpb >>= 1)
-    if ((size_t)make_geom(c, wpb).wave_bytes * wpb <= 64 * 1024) return wpb;
-  return 0;
+    if ((size_t)make_geom(c, wpb, 0, full).wave_bytes * wpb <= LDS_SOFT) return wpb;
+  return (size_t)make_geom(c, 1, 0, full).wave_bytes <= LDS_HARD ? 1 : 0;
 }
 
 int check(const d2d_cfg *c, const d2d_state *s) {
@@ -1498,26 +1704,25 @@ int launch_stages(const d2d_cfg *c, const d2d_state *s, uint32_t stages, void *s
   if (c->B == 0) return 0;
   d2d_state st = *s;
   if (!st.action) st.action = (const double D2D_AS *)st.drone;  // never dereferenced meaningfully without CONTROL
-#ifndef D2D_NO_SPEC
-  if (spec_default_matches(*c) && c->N > spec_ncap(2)) {
+  if (spec_path(*c) && c->N > spec_ncap(2)) {
     const int wpb = pick_wpb(*c);
-    const Geom g = make_geom(*c, wpb);
+    const Geom g = make_geom(*c, wpb, 0, true);
     const dim3 grid((c->B + wpb - 1) / wpb), block(WAVE * wpb);
+    lds_optin(k_stages<3>, (size_t)g.wave_bytes * wpb);
     hipLaunchKernelGGL(k_stages<3>, grid, block, (size_t)g.wave_bytes * wpb, (hipStream_t)stream, *c, st, stages, pin,
                        coll_out);
-  } else if (spec_default_matches(*c)) {
+  } else if (spec_path(*c)) {
     const int spec = c->N <= spec_ncap(1) ? 1 : 2;
-    const Geom g = make_geom(*c, WAVES_PER_BLOCK, spec_ncap(spec));
+    const Geom g = make_geom(*c, WAVES_PER_BLOCK, spec_ncap(spec), true);
     const dim3 grid((c->B + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK), block(WAVE * WAVES_PER_BLOCK);
     const size_t lds = (size_t)g.wave_bytes * WAVES_PER_BLOCK;
     if (spec == 1) hipLaunchKernelGGL(k_stages<1>, grid, block, lds, (hipStream_t)stream, *c, st, stages, pin, coll_out);
     else hipLaunchKernelGGL(k_stages<2>, grid, block, lds, (hipStream_t)stream, *c, st, stages, pin, coll_out);
-  } else
-#endif
-  {
+  } else {
     const int wpb = pick_wpb(*c);
     const Geom g = make_geom(*c, wpb);
     const dim3 grid((c->B + wpb - 1) / wpb), block(WAVE * wpb);
+    lds_optin(k_stages<0>, (size_t)g.wave_bytes * wpb);
     hipLaunchKernelGGL(k_stages<0>, grid, block, (size_t)g.wave_bytes * wpb, (hipStream_t)stream, *c, st, stages, pin,
                        coll_out);
   }
@@ -1557,14 +1762,14 @@ int plan_check(const d2d_cfg *c, const d2d_state *s, const d2d_plan *p) {
     if (p->nu <= 0 || p->n_sample <= 0 || p->n_ts <= 0 || p->traj_cap < p->n_ts || p->node_cap < 2)
       return fail(-1, "plan: bad planner dimensions");
     if (!s->plan_ok || !s->wp_valid || !s->wp) return fail(-1, "plan: plan_ok / wp_valid / wp buffers missing");
-    if ((size_t)plan_wave_bytes(c->N, p->nu, p->n_sample, c->W * c->H) > 64 * 1024) return fail(-4, "plan: too many agents for the tracker staging in LDS");
+    if ((size_t)plan_wave_bytes(c->N, p->nu, p->n_sample, c->W * c->H) > LDS_HARD) return fail(-4, "plan: too many agents for the tracker staging in LDS");
   }
   if (p->gaze == D2D_GAZE_OXFORD) {
     if (!p->yaw_space || !p->tobs_tab || !p->pw_leaf || !p->pw_tree || !p->pw_rowleaf || !p->seen_step) return fail(-1, "plan: null gaze pointer");
     if (!s->action) return fail(-1, "plan: null action buffer");
     if (p->n_yaw <= 0 || p->n_yaw > 7) return fail(-4, "gaze: at most 7 yaw-rate candidates");
     if (p->pw_nleaf <= 0 || p->pw_nprog != 2 * p->pw_nleaf - 1 || p->pw_ntree < 3) return fail(-1, "gaze: bad pairwise-sum program");
-    if ((size_t)gaze_geom(*c, *p).wave_bytes > 64 * 1024)
+    if ((size_t)gaze_geom(*c, *p).wave_bytes > LDS_HARD)
       return fail(-4, "gaze: map / view depth too large for the per-env LDS working set");
     if (gaze_geom(*c, *p).bbn > 64 || c->W * c->H < 64)
       return fail(-4, "gaze: view depth above 29 cells or a map below 64 cells");
@@ -1578,9 +1783,10 @@ int gaze_launch(const d2d_cfg *c, const d2d_state *s, const d2d_plan *p, const d
   if ((p->gaze != D2D_GAZE_OXFORD && !init) || c->B == 0) return 0;
   const size_t wb = p->gaze == D2D_GAZE_OXFORD ? (size_t)gaze_geom(*c, *p).wave_bytes : 0;
   int wpb = WAVES_PER_BLOCK;
-  while (wpb > 1 && wb * wpb > 64 * 1024) wpb >>= 1;
+  while (wpb > 1 && wb * wpb > LDS_SOFT) wpb >>= 1;
   const dim3 grid((c->B + wpb - 1) / wpb), block(WAVE * wpb);
   const size_t lds = wb * wpb;
+  lds_optin(k_gaze, lds);
   hipLaunchKernelGGL(k_gaze, grid, block, lds, (hipStream_t)stream, *c, *s, *p, init ? *init : *s, init ? 1 : (skip_done ? 2 : 0));
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return fail(-3, hipGetErrorString(err));
@@ -1591,9 +1797,10 @@ int plan_launch(const d2d_cfg *c, const d2d_state *s, const d2d_plan *p, bool sk
   if (p->planner != D2D_PLAN_PRIMITIVE || c->B == 0) return 0;
   const size_t wb = (size_t)plan_wave_bytes(c->N, p->nu, p->n_sample, c->W * c->H);
   int wpb = WAVES_PER_BLOCK;
-  while (wpb > 1 && wb * wpb > 64 * 1024) wpb >>= 1;
+  while (wpb > 1 && wb * wpb > LDS_SOFT) wpb >>= 1;
   const dim3 grid((c->B + wpb - 1) / wpb), block(WAVE * wpb);
   const size_t lds = wb * wpb;
+  lds_optin(k_plan, lds);
   hipLaunchKernelGGL(k_plan, grid, block, lds, (hipStream_t)stream, *c, *s, *p, skip_done ? 1 : 0);
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return fail(-3, hipGetErrorString(err));
@@ -1696,19 +1903,21 @@ int d2d_closed_loop(const d2d_cfg *c, const d2d_state *s, const d2d_plan *p, int
   if (c->planner_mode == D2D_PLANNER_EXTERNAL && p->launch_args && (p->planner == D2D_PLAN_PRIMITIVE || p->gaze == D2D_GAZE_OXFORD)) {
     // one persistent launch: every wave loops over the steps of its own env.  Specialisation as for the step kernel;
     // as many envs (waves) per workgroup as the largest phase's LDS working set allows
-    const int spec = !spec_default_matches(*c) ? 0 : (c->N <= spec_ncap(1) ? 1 : (c->N <= spec_ncap(2) ? 2 : 3));
+    const int spec = !spec_path(*c) ? 0 : (c->N <= spec_ncap(1) ? 1 : (c->N <= spec_ncap(2) ? 2 : 3));
     auto bytes = [&](int wpb) {
       return spec == 0 ? closed_wave_bytes<0>(*c, *p, wpb) : spec == 1 ? closed_wave_bytes<1>(*c, *p, wpb)
            : spec == 2 ? closed_wave_bytes<2>(*c, *p, wpb) : closed_wave_bytes<3>(*c, *p, wpb);
     };
     int wpb = (spec == 1 || spec == 2) ? WAVES_PER_BLOCK : pick_wpb(*c);
-    while (wpb >= 1 && (size_t)bytes(wpb) * wpb > 64 * 1024) wpb = (spec == 1 || spec == 2) ? 0 : wpb / 2;
+    while (wpb >= 1 && (size_t)bytes(wpb) * wpb > (wpb == 1 ? LDS_HARD : LDS_SOFT)) wpb = (spec == 1 || spec == 2) ? 0 : wpb / 2;
     if (wpb >= 1) {
       const dim3 grid((c->B + wpb - 1) / wpb), block(WAVE * wpb);
       const size_t lds = (size_t)bytes(wpb) * wpb;
       ClosedArgs *dev = (ClosedArgs *)p->launch_args;
       hipLaunchKernelGGL(k_closed_args, dim3(1), dim3(64), 0, (hipStream_t)stream, dev, *c, *s, *p, auto_reset ? *init : *s,
                          (int)on_done, (int)nsteps);
+      if (spec == 0) lds_optin(k_closed<0>, lds);
+      if (spec == 3) lds_optin(k_closed<3>, lds);
       switch (spec) {
         case 0: hipLaunchKernelGGL(k_closed<0>, grid, block, lds, (hipStream_t)stream, (const ClosedArgs *)dev); break;
         case 1: hipLaunchKernelGGL(k_closed<1>, grid, block, lds, (hipStream_t)stream, (const ClosedArgs *)dev); break;
