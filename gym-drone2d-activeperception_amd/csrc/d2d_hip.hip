@@ -1618,6 +1618,12 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK, D2D_MIN_WAVES) void k_closed
   const int nsteps = a->nsteps;
   const bool freeze = a->on_done == D2D_DONE_FREEZE;
   int nsearch = 0;
+#ifdef D2D_CHAIN_PROF
+  // Diagnostic build only (tools/chain_prof.py): how long this env's chain of steps ran (shader clocks) and how much of it
+  // its searches took -- the launch lasts as long as the longest chain.
+  const unsigned long long cp0 = __builtin_amdgcn_s_memtime();
+  unsigned long long cps = 0;
+#endif
 #pragma unroll 1
   for (int t = 0; t < nsteps; ++t) {
     if (freeze && a->s.flags[(size_t)e * 4 + D2D_F_DONE] != 0) break;  // one episode per env: it stays as it ended
@@ -1629,14 +1635,27 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK, D2D_MIN_WAVES) void k_closed
       if (nsearch * 32 > t + 16) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);
       ph_gaze_stages<SPEC, D2D_ST_PERCEIVE>(a, e, off);
       if (__builtin_amdgcn_readfirstlane(ph_plan_quick<SPEC>(a, e, off))) {
+#ifdef D2D_CHAIN_PROF
+        const unsigned long long s0 = __builtin_amdgcn_s_memtime();
+#endif
         ph_plan_search<SPEC>(a, e, off);
         nsearch += 1;
+#ifdef D2D_CHAIN_PROF
+        cps += __builtin_amdgcn_s_memtime() - s0;
+#endif
       }
       ph_stages<SPEC, D2D_ST_ACT>(a, e, off);
     } else {
       ph_gaze_stages<SPEC, D2D_ST_ALL>(a, e, off);
     }
   }
+#ifdef D2D_CHAIN_PROF
+  if ((threadIdx.x & (WAVE - 1)) == 0 && a->p.plan_stat) {
+    const unsigned long long tot = __builtin_amdgcn_s_memtime() - cp0;
+    a->p.plan_stat[(size_t)e * 4 + 1] = (int)(tot >> 4);   // 16-clock units
+    a->p.plan_stat[(size_t)e * 4 + 2] = (int)(cps >> 4);
+  }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------

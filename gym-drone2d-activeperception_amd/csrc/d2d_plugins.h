@@ -879,7 +879,7 @@ __host__ __device__ inline GazeGeom gaze_geom(const d2d_cfg &c, const d2d_plan &
   // int swept index + double reward + candidate bits per box cell, block sums + add stacks per candidate, the plan
   const int sums = 8 * p.n_yaw * (2 * p.pw_nleaf - 1), live = 4 * g.ncell;  // the live-cell list shares the sums' space
   const int bytes = 4 * g.ncell + 8 * g.ncell + ((g.ncell + 7) & ~7) + (((sums > live ? sums : live) + 7) & ~7) + 8 * 16 +
-                    4 * (4 * p.pw_nleaf + p.pw_ntree);
+                    4 * (4 * p.pw_nleaf + p.pw_ntree) + 16;  // + the row range of the cells that carry a non-zero term
   g.wave_bytes = (bytes + 15) & ~15;
   return g;
 }
@@ -909,6 +909,7 @@ __device__ __forceinline__ void gaze_env(const d2d_cfg &c, const d2d_state &s, c
   int *pwl = swi + g.ncell;                                       // [pw_nleaf][4] + [pw_ntree]: the pairwise plan
   int *pwp = pwl + 4 * p.pw_nleaf;
   unsigned char *cm = (unsigned char *)(pwp + p.pw_ntree);        // [ncell]
+  int *rng = (int *)(cm + ((g.ncell + 7) & ~7));                  // [2] first / last grid row with a non-zero term of any sum
   const int W = c.W, H = c.H;
   const double deg2rad = 0x1.1df46a2529d39p-6;                    // math.radians
   const double depth2 = c.depth * c.depth;
@@ -1001,6 +1002,18 @@ __device__ __forceinline__ void gaze_env(const d2d_cfg &c, const d2d_state &s, c
   //      the head (d2 <= depth^2, about half of the box) can carry a view bit; every other cell contributes 0 to all
   //      six sums whatever its reward.  Those live cells are compacted first (ballot + prefix count into the `swl`
   //      list), so the expensive part runs on ~4 full passes instead of 7 sparse ones ----
+  // half angle of the sector that holds every candidate's view: half_fov + max |yaw step| + 3 degrees; the pre-test only
+  // applies while that stays below 87 degrees (cos^2 evaluated in double from a float cosine, shrunk by 2 % on top)
+  double wide2 = 0.0;
+  {
+    double span = 0.0;
+    for (int a = 0; a < p.n_yaw; ++a) span = fmax(span, fabs(p.yaw_space[a]) * c.dt);
+    const double wide = p.half_fov + (span + 3.0) * deg2rad;
+    if (wide < 1.518 && span <= 90.0) {
+      const double cw = (double)cosf((float)wide) * 0.98;
+      wide2 = cw * cw;
+    }
+  }
   int nlive = 0;
   for (int q0 = 0; q0 < g.ncell; q0 += WAVE) {
     const int q = q0 + lane;
@@ -1010,13 +1023,22 @@ __device__ __forceinline__ void gaze_env(const d2d_cfg &c, const d2d_state &s, c
     bool live = false;
     if (q < g.ncell) {
       const double ca = hx - (double)i * c.scale, cb = hy - (double)j * c.scale;
-      live = (i >= 0) & (i < W) & (j >= 0) & (j < H) & (ca * ca + cb * cb <= depth2);
+      const double d2 = ca * ca + cb * cb;
+      // every candidate looks within `wide` of the drone's current direction (its own half angle + the largest yaw step, with
+      // degrees of slack): a cell outside that sector carries no view bit.  cos^2 of the sector's half angle is `wide2`.
+      const double dm = (-ca) * cone[7].cy + (-cb) * cone[7].sy;
+      const bool sector = (wide2 <= 0.0) | (d2 <= 0.0) | ((dm > 0.0) & (dm * dm >= wide2 * d2));
+      live = (i >= 0) & (i < W) & (j >= 0) & (j < H) & (d2 <= depth2) & sector;
       rew[q] = 0.0;
       cm[q] = 0;
     }
     const unsigned long long lm = __ballot(live);
     if (live) swl[nlive + __popcll(lm & ((1ull << lane) - 1ull))] = q;
     nlive += __popcll(lm);
+  }
+  if (lane == 0) {
+    rng[0] = 0x7fffffff;
+    rng[1] = -1;
   }
   wave_sync_lds();
 #if defined(D2D_GAZE_ABL) && D2D_GAZE_ABL == 3
@@ -1036,6 +1058,7 @@ __device__ __forceinline__ void gaze_env(const d2d_cfg &c, const d2d_state &s, c
     double tobs[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) tobs[u] = sn[u] > 0 ? p.tobs_tab[call - min(sn[u], call)] : p.tobs_tab[p.tobs_len + call];
+    int hot_lo = 0x7fffffff, hot_hi = -1;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       if (l0 + u * WAVE + lane < nlive) {
@@ -1079,9 +1102,19 @@ __device__ __forceinline__ void gaze_env(const d2d_cfg &c, const d2d_state &s, c
             }
           }
         }
+        // A cell adds view * reward to a sum: nothing unless it is seen by some candidate AND its reward is non-zero (rewards
+        // are >= +0.0, and x + 0.0 == x), and the cells the drone sees right now have reward 0 -- most of every candidate's
+        // view.  Only the rows that hold such a cell take part in the sums below.
+        const bool hot = (bits != 0u) & (rw != 0.0);
         rew[q] = rw;
-        cm[q] = (unsigned char)bits;
+        cm[q] = hot ? (unsigned char)bits : (unsigned char)0;
+        hot_lo = hot ? min(hot_lo, i) : hot_lo;
+        hot_hi = hot ? max(hot_hi, i) : hot_hi;
       }
+    }
+    if (hot_hi >= 0) {
+      atomicMin(&rng[0], hot_lo);
+      atomicMax(&rng[1], hot_hi);
     }
   }
   wave_sync_lds();
@@ -1098,7 +1131,11 @@ __device__ __forceinline__ void gaze_env(const d2d_cfg &c, const d2d_state &s, c
   // ~2000 of a (candidate, r) mapping whose lanes walk every slot of every block.
   const FastDiv fdh(H);
   const int jlo = max(bj, 0), jhi = min(bj + g.bbn, H);  // columns of the box inside the map
-  const int row_lo = max(bi, 0), row_hi = min(bi + g.bbn - 1, W - 1);
+  const int row_lo = rng[0], row_hi = rng[1];            // rows of the box (inside the map) with a non-zero term
+  if (row_hi < row_lo) {  // every sum is 0: `max_reward < 0` never holds, the first candidate stays (yaw_planner.py:116-125)
+    if (lane == 0) act[e] = p.yaw_space[0] / p.yaw_rate_max;
+    return;
+  }
   int lf_lo = 0, lf_hi = -1;
   if (jlo < jhi && row_lo <= row_hi) {  // blocks the box rows can touch: a contiguous range
     lf_lo = p.pw_rowleaf[row_lo];

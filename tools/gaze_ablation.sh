@@ -6,7 +6,7 @@ cd /tmp && export TMPDIR=/tmp
 for n in 1 2 3 4 5 full; do
   lib=libd2d_abl$n.so; [ $n = full ] && lib=libd2d_hip.so
   rm -rf $ROOT/gpurun_out/gabl/$n
-  D2D_LIB=$ROOT/gym-drone2d-activeperception_amd/csrc/$lib timeout -k 10 200 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES --output-format csv -d $ROOT/gpurun_out/gabl/$n -- python3 $ROOT/bench.py --no-persistent --steps 60 --warmup 40 --no-cpu-baseline --no-step-kernel --workers 0 --envs 1024 > $ROOT/gpurun_out/gabl_$n.log 2>&1
+  D2D_LIB=$ROOT/gym-drone2d-activeperception_amd/csrc/$lib timeout -k 10 200 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES --output-format csv -d $ROOT/gpurun_out/gabl/$n -- python3 $ROOT/bench.py --no-persistent --steps 60 --warmup 40 --no-cpu-baseline --leg closed --prologue 200 --workers 0 --envs 1024 > $ROOT/gpurun_out/gabl_$n.log 2>&1
   python3 - <<PY
 import csv,glob,collections
 f=glob.glob("$ROOT/gpurun_out/gabl/$n/**/*counter_collection.csv",recursive=True)[0]
