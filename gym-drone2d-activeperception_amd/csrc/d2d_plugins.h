@@ -866,6 +866,34 @@ __device__ __forceinline__ void plan_reset_env(const d2d_cfg &c, const d2d_plan 
     for (size_t i = lane; i < WH; i += WAVE) p.seen_step[e * WH + i] = 0;
 }
 
+
+// Cells whose ORIGIN can lie in the sector {|p - c| <= depth, angle(p - c, dir) <= w}: a box [i_lo, i_hi] x [j_lo, j_hi], one
+// cell of margin on every side (float arithmetic on purpose: the box only has to CONTAIN the sector; the exact per-cell tests
+// decide).  `cw`, `sw`: cos / sin of w; (dx, dy): the unit view direction.  Clipped to `lo` / `hi` bounds given by the caller.
+struct CellBox {
+  int i_lo, i_hi, j_lo, j_hi;
+};
+__device__ __forceinline__ CellBox sector_box(double cx, double cy, double depth, double inv_scale, double ddx, double ddy,
+                                              float cw, float sw) {
+  const float dx = (float)ddx, dy = (float)ddy;
+  // edge directions dir rotated by +-w, the apex (0), and the axis directions that lie inside the sector
+  const float ex0 = dx * cw - dy * sw, ey0 = dy * cw + dx * sw, ex1 = dx * cw + dy * sw, ey1 = dy * cw - dx * sw;
+  const float m = cw - 0.02f;  // an axis is inside when its cosine with dir is >= cos w (slack towards "inside")
+  float xmax = fmaxf(0.f, fmaxf(ex0, ex1)), xmin = fminf(0.f, fminf(ex0, ex1));
+  float ymax = fmaxf(0.f, fmaxf(ey0, ey1)), ymin = fminf(0.f, fminf(ey0, ey1));
+  xmax = dx >= m ? 1.f : xmax;
+  xmin = -dx >= m ? -1.f : xmin;
+  ymax = dy >= m ? 1.f : ymax;
+  ymin = -dy >= m ? -1.f : ymin;
+  const float d = (float)depth * 1.001f + 0.01f, is = (float)inv_scale, fx = (float)cx, fy = (float)cy;
+  CellBox b;
+  b.i_lo = (int)floorf((fx + d * xmin) * is) - 1;
+  b.i_hi = (int)floorf((fx + d * xmax) * is) + 1;
+  b.j_lo = (int)floorf((fy + d * ymin) * is) - 1;
+  b.j_hi = (int)floorf((fy + d * ymax) * is) + 1;
+  return b;
+}
+
 struct GazeGeom {
   int bbn;    // cells per axis of the bounding box of a view disk
   int ncell;  // bbn * bbn
@@ -958,15 +986,32 @@ __device__ __forceinline__ void gaze_env(const d2d_cfg &c, const d2d_state &s, c
     cone[a].sy = vdir[2 * a + 1];
   }
   // ---- t_i: cells the current pose sees (yaw_planner.py:93-97); only the box around the drone can be seen ----
+  // cos / sin of the pre-test sectors (float, with degrees of slack): the drone's own view, and the sector that holds every
+  // candidate's view (half_fov + the largest yaw step)
+  double span_deg = 0.0;
+  for (int a = 0; a < p.n_yaw; ++a) span_deg = fmax(span_deg, fabs(p.yaw_space[a]) * c.dt);
+  const float w_own = (float)p.half_fov + 2.0f * 0.0174533f, w_all = (float)p.half_fov + ((float)span_deg + 3.0f) * 0.0174533f;
+  const bool boxes = w_all < 1.518f && span_deg <= 90.0;  // else: the whole disk's box, no sector pre-test
   {
     const int bi = (int)floor((x0 - c.depth) * inv_scale) - 1, bj = (int)floor((y0 - c.depth) * inv_scale) - 1;
-    for (int q0 = 0; q0 < g.ncell; q0 += WAVE) {
-      const int q = q0 + lane;
-      int r, cc;
-      fdb.divmod(q, r, cc);
-      const int i = bi + r, j = bj + cc;
-      if (q < g.ncell && i >= 0 && i < W && j >= 0 && j < H) {
-        if (view_cell(p, depth2, quick, x0, y0, cone[7], (double)i * c.scale, (double)j * c.scale)) seen[i * H + j] = call;
+    CellBox b;
+    b.i_lo = bi; b.i_hi = bi + g.bbn - 1; b.j_lo = bj; b.j_hi = bj + g.bbn - 1;
+    if (boxes) {
+      const CellBox sb = sector_box(x0, y0, c.depth, inv_scale, cone[7].cy, cone[7].sy, __cosf(w_own), __sinf(w_own));
+      b.i_lo = max(b.i_lo, sb.i_lo); b.i_hi = min(b.i_hi, sb.i_hi); b.j_lo = max(b.j_lo, sb.j_lo); b.j_hi = min(b.j_hi, sb.j_hi);
+    }
+    b.i_lo = max(b.i_lo, 0); b.i_hi = min(b.i_hi, W - 1); b.j_lo = max(b.j_lo, 0); b.j_hi = min(b.j_hi, H - 1);
+    const int nc = b.j_hi - b.j_lo + 1, nsub = (b.i_hi - b.i_lo + 1) * nc;
+    if (nc > 0 && nsub > 0) {
+      const FastDiv fds(nc);
+      for (int q0 = 0; q0 < nsub; q0 += WAVE) {
+        const int q = q0 + lane;
+        int r, cc;
+        fds.divmod(q, r, cc);
+        const int i = b.i_lo + r, j = b.j_lo + cc;
+        if (q < nsub) {
+          if (view_cell(p, depth2, quick, x0, y0, cone[7], (double)i * c.scale, (double)j * c.scale)) seen[i * H + j] = call;
+        }
       }
     }
   }
@@ -1002,43 +1047,50 @@ __device__ __forceinline__ void gaze_env(const d2d_cfg &c, const d2d_state &s, c
   //      the head (d2 <= depth^2, about half of the box) can carry a view bit; every other cell contributes 0 to all
   //      six sums whatever its reward.  Those live cells are compacted first (ballot + prefix count into the `swl`
   //      list), so the expensive part runs on ~4 full passes instead of 7 sparse ones ----
-  // half angle of the sector that holds every candidate's view: half_fov + max |yaw step| + 3 degrees; the pre-test only
-  // applies while that stays below 87 degrees (cos^2 evaluated in double from a float cosine, shrunk by 2 % on top)
+  // Live cells = box cells inside the map, inside the head's view disk AND inside the sector that holds every candidate's view
+  // (`w_all` around the drone's current direction); only the box of that sector is walked.  cos^2 of the sector's half angle
+  // (double from a float cosine, shrunk by 2 %) for the per-cell pre-test.
   double wide2 = 0.0;
-  {
-    double span = 0.0;
-    for (int a = 0; a < p.n_yaw; ++a) span = fmax(span, fabs(p.yaw_space[a]) * c.dt);
-    const double wide = p.half_fov + (span + 3.0) * deg2rad;
-    if (wide < 1.518 && span <= 90.0) {
-      const double cw = (double)cosf((float)wide) * 0.98;
-      wide2 = cw * cw;
-    }
+  if (boxes) {
+    const double cwd = (double)__cosf(w_all) * 0.98;
+    wide2 = cwd * cwd;
   }
+  for (int k = lane; k < (g.ncell + 3) / 4; k += WAVE) ((unsigned int *)cm)[k] = 0u;  // no view bits anywhere else in the box
   int nlive = 0;
-  for (int q0 = 0; q0 < g.ncell; q0 += WAVE) {
-    const int q = q0 + lane;
-    int r, cc;
-    fdb.divmod(q, r, cc);
-    const int i = bi + r, j = bj + cc;
-    bool live = false;
-    if (q < g.ncell) {
-      const double ca = hx - (double)i * c.scale, cb = hy - (double)j * c.scale;
-      const double d2 = ca * ca + cb * cb;
-      // every candidate looks within `wide` of the drone's current direction (its own half angle + the largest yaw step, with
-      // degrees of slack): a cell outside that sector carries no view bit.  cos^2 of the sector's half angle is `wide2`.
-      const double dm = (-ca) * cone[7].cy + (-cb) * cone[7].sy;
-      const bool sector = (wide2 <= 0.0) | (d2 <= 0.0) | ((dm > 0.0) & (dm * dm >= wide2 * d2));
-      live = (i >= 0) & (i < W) & (j >= 0) & (j < H) & (d2 <= depth2) & sector;
-      rew[q] = 0.0;
-      cm[q] = 0;
+  {
+    CellBox b;
+    b.i_lo = bi; b.i_hi = bi + g.bbn - 1; b.j_lo = bj; b.j_hi = bj + g.bbn - 1;
+    if (boxes) {
+      const CellBox sb = sector_box(hx, hy, c.depth, inv_scale, cone[7].cy, cone[7].sy, __cosf(w_all), __sinf(w_all));
+      b.i_lo = max(b.i_lo, sb.i_lo); b.i_hi = min(b.i_hi, sb.i_hi); b.j_lo = max(b.j_lo, sb.j_lo); b.j_hi = min(b.j_hi, sb.j_hi);
     }
-    const unsigned long long lm = __ballot(live);
-    if (live) swl[nlive + __popcll(lm & ((1ull << lane) - 1ull))] = q;
-    nlive += __popcll(lm);
+    b.i_lo = max(b.i_lo, 0); b.i_hi = min(b.i_hi, W - 1); b.j_lo = max(b.j_lo, 0); b.j_hi = min(b.j_hi, H - 1);
+    const int nc = b.j_hi - b.j_lo + 1, nsub = (nc > 0 && b.i_hi >= b.i_lo) ? (b.i_hi - b.i_lo + 1) * nc : 0;
+    const FastDiv fds(nc > 0 ? nc : 1);
+    for (int q0 = 0; q0 < nsub; q0 += WAVE) {
+      const int qs = q0 + lane;
+      int r, cc;
+      fds.divmod(qs, r, cc);
+      const int i = b.i_lo + r, j = b.j_lo + cc;
+      const int q = (i - bi) * g.bbn + (j - bj);  // index in the disk's box: rows of the grid in order, ascending with qs
+      bool live = false;
+      if (qs < nsub) {
+        const double ca = hx - (double)i * c.scale, cb = hy - (double)j * c.scale;
+        const double d2 = ca * ca + cb * cb;
+        const double dm = (-ca) * cone[7].cy + (-cb) * cone[7].sy;
+        const bool sector = (wide2 <= 0.0) | (d2 <= 0.0) | ((dm > 0.0) & (dm * dm >= wide2 * d2));
+        live = (d2 <= depth2) & sector;
+      }
+      const unsigned long long lm = __ballot(live);
+      if (live) swl[nlive + __popcll(lm & ((1ull << lane) - 1ull))] = q;
+      nlive += __popcll(lm);
+    }
   }
   if (lane == 0) {
-    rng[0] = 0x7fffffff;
-    rng[1] = -1;
+    rng[0] = 0;   // box rows / box columns (bit = index in the disk's box, two words each: bbn <= 64) that hold a non-zero term
+    rng[1] = 0;
+    rng[2] = 0;
+    rng[3] = 0;
   }
   wave_sync_lds();
 #if defined(D2D_GAZE_ABL) && D2D_GAZE_ABL == 3
@@ -1058,7 +1110,7 @@ __device__ __forceinline__ void gaze_env(const d2d_cfg &c, const d2d_state &s, c
     double tobs[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) tobs[u] = sn[u] > 0 ? p.tobs_tab[call - min(sn[u], call)] : p.tobs_tab[p.tobs_len + call];
-    int hot_lo = 0x7fffffff, hot_hi = -1;
+    unsigned int hr0 = 0, hr1 = 0, hc0 = 0, hc1 = 0;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       if (l0 + u * WAVE + lane < nlive) {
@@ -1108,13 +1160,18 @@ __device__ __forceinline__ void gaze_env(const d2d_cfg &c, const d2d_state &s, c
         const bool hot = (bits != 0u) & (rw != 0.0);
         rew[q] = rw;
         cm[q] = hot ? (unsigned char)bits : (unsigned char)0;
-        hot_lo = hot ? min(hot_lo, i) : hot_lo;
-        hot_hi = hot ? max(hot_hi, i) : hot_hi;
+        const unsigned int hb = hot ? 1u : 0u;
+        hr0 |= r < 32 ? hb << (r & 31) : 0u;
+        hr1 |= r < 32 ? 0u : hb << (r & 31);
+        hc0 |= cc < 32 ? hb << (cc & 31) : 0u;
+        hc1 |= cc < 32 ? 0u : hb << (cc & 31);
       }
     }
-    if (hot_hi >= 0) {
-      atomicMin(&rng[0], hot_lo);
-      atomicMax(&rng[1], hot_hi);
+    if ((hr0 | hr1) != 0u) {
+      if (hr0) atomicOr((unsigned int *)&rng[0], hr0);
+      if (hr1) atomicOr((unsigned int *)&rng[1], hr1);
+      if (hc0) atomicOr((unsigned int *)&rng[2], hc0);
+      if (hc1) atomicOr((unsigned int *)&rng[3], hc1);
     }
   }
   wave_sync_lds();
@@ -1130,33 +1187,38 @@ __device__ __forceinline__ void gaze_env(const d2d_cfg &c, const d2d_state &s, c
   // shuffles per candidate.  (Block offsets are multiples of 8, so g % 8 == r.)  ~800 instructions instead of the
   // ~2000 of a (candidate, r) mapping whose lanes walk every slot of every block.
   const FastDiv fdh(H);
-  const int jlo = max(bj, 0), jhi = min(bj + g.bbn, H);  // columns of the box inside the map
-  const int row_lo = rng[0], row_hi = rng[1];            // rows of the box (inside the map) with a non-zero term
-  if (row_hi < row_lo) {  // every sum is 0: `max_reward < 0` never holds, the first candidate stays (yaw_planner.py:116-125)
+  const unsigned long long hrows = ((unsigned long long)(unsigned int)rng[1] << 32) | (unsigned int)rng[0];
+  const unsigned long long hcols = ((unsigned long long)(unsigned int)rng[3] << 32) | (unsigned int)rng[2];
+  if (hrows == 0ull) {  // every sum is 0: `max_reward < 0` never holds, the first candidate stays (yaw_planner.py:116-125)
     if (lane == 0) act[e] = p.yaw_space[0] / p.yaw_rate_max;
     return;
   }
-  int lf_lo = 0, lf_hi = -1;
-  if (jlo < jhi && row_lo <= row_hi) {  // blocks the box rows can touch: a contiguous range
-    lf_lo = p.pw_rowleaf[row_lo];
-    lf_hi = p.pw_rowleaf[row_hi];
-    while (lf_hi + 1 < p.pw_nleaf && pwl[4 * (lf_hi + 1)] < (row_hi + 1) * H) ++lf_hi;
+  // rows / columns of the grid that hold a non-zero term (they lie inside the box and inside the map)
+  const int row_lo = bi + __ffsll((long long)hrows) - 1, row_hi = bi + 63 - __clzll((long long)hrows);
+  const int jlo = bj + __ffsll((long long)hcols) - 1, jhi = bj + 64 - __clzll((long long)hcols);
+  int lf_lo = p.pw_rowleaf[row_lo], lf_hi = p.pw_rowleaf[row_hi];  // the blocks those rows can touch: a contiguous range
+  while (lf_hi + 1 < p.pw_nleaf && pwl[4 * (lf_hi + 1)] < (row_hi + 1) * H) ++lf_hi;
+  for (int k = lane; k < p.n_yaw * nnode; k += WAVE) lsum[k] = 0.0;  // blocks without a non-zero term sum to 0
+  // the blocks of that range that cover a row with a non-zero term, compacted: lane = block, in order
+  int *hlist = swi;  // the swept map is not needed any more
+  int nhl = 0;
+  for (int l0 = lf_lo; l0 <= lf_hi; l0 += WAVE) {
+    const int lf = min(l0 + lane, lf_hi);
+    const int i_first = pwl[4 * lf + 2], i_last = pwl[4 * lf + 3];
+    const int lo = max(i_first - bi, 0), hi = min(i_last - bi, 63);
+    const bool hotl = (l0 + lane <= lf_hi) && lo <= hi && ((hrows >> lo) & ((hi - lo >= 63) ? ~0ull : ((1ull << (hi - lo + 1)) - 1ull))) != 0ull;
+    const unsigned long long hm = __ballot(hotl);
+    if (hotl) hlist[nhl + __popcll(hm & ((1ull << lane) - 1ull))] = lf;
+    nhl += __popcll(hm);
   }
-  {
-    const FastDiv fdl(p.pw_nleaf);  // no integer division: ~20 instructions each here
-    for (int k = lane; k < p.n_yaw * p.pw_nleaf; k += WAVE) {
-      int a, lf;
-      fdl.divmod(k, a, lf);
-      if (lf < lf_lo || lf > lf_hi) lsum[a * nnode + lf] = 0.0;  // the others sum to 0
-    }
-  }
-  const int nchain = 8 * (lf_hi - lf_lo + 1);
-  const int per_row = (g.bbn + 7) >> 3;  // cells of one residue in a box row, at most
+  wave_sync_lds();
+  const int nchain = 8 * nhl;
+  const int per_row = (min(jhi - jlo, g.bbn) + 7 + 7) >> 3;  // cells of one residue among the columns with a non-zero term, at most
   const int max_span = 127 / H + 2;      // grid rows a block of <= 128 cells can touch
   for (int c0 = 0; c0 < nchain; c0 += WAVE) {
     const int ch = c0 + lane;
     const bool live = ch < nchain;
-    const int lf = lf_lo + min(ch, nchain - 1) / 8, r_of = lane & 7;
+    const int lf = hlist[min(ch, nchain - 1) / 8], r_of = lane & 7;
     const int off = pwl[4 * lf], m = pwl[4 * lf + 1], i_first = pwl[4 * lf + 2], i_last = pwl[4 * lf + 3];
     const int gend = off + (m - (m & 7));  // the last m % 8 elements of a block are added after its fold
     double acc[7];
