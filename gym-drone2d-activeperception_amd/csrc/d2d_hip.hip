@@ -232,7 +232,9 @@ struct CellDiv {
       : inv(1.0f / (float)scale), s((int)scale), by10(scale == 10.0 && max_px <= 81919.0) {}
   __device__ __forceinline__ int operator()(double v) const {
     const int vi = __double2int_rz(v);  // truncation == floor for v >= 0; saturates / 0 for wild or NaN inputs
-    if (by10) return (int)(((unsigned int)vi * 52429u) >> 19);  // a live sample lies inside the map; others are clamped by the caller
+    // a live sample lies inside the map (0 <= vi < 81920 < 2^24, product < 2^32): a full-rate 24-bit multiply; a dead lane's
+    // garbage is masked to 24 bits by the instruction and ignored by the caller
+    if (by10) return (int)(__umul24((unsigned int)vi, 52429u) >> 19);
     int q = (int)((float)vi * inv);
     const int r = vi - q * s;
     q += (r >= s) ? 1 : 0;
@@ -863,54 +865,35 @@ __device__ __forceinline__ void dyn_full(const d2d_cfg &c, const d2d_state &s, i
   bool small = true;
   for (int k = lane; k < N; k += WAVE) small = small && (L.pu[k] <= 1 && L.nu[k] <= 1);
   if (__all(small)) {
-    // blocks of at most 3 x 3 cells: fixed trip counts, the cells of a block at constant offsets of one index
-    for (int k0 = 0; k0 < N; k0 += WAVE) {
-      const int k = k0 + lane, kc = min(k, N - 1);
-      const bool on = k < N;
-      const int ncx = L.ncx[kc], ncy = L.ncy[kc], nu = L.nu[kc];
-      const unsigned int nval = on ? block_valid9(ncx, ncy, nu, W, H) : 0u;
-#pragma unroll
-      for (int q = 0; q < 9; ++q) {
-        const int di = q / 3 - 1, dj = q % 3 - 1;
-        if ((nval >> q) & 1u) {
-          const int idx = (ncx + di) * H + (ncy + dj);
-          g8[idx] = g8[idx] | 0x80;
-        }
-      }
+    // blocks of at most 3 x 3 cells: lane = (agent, cell of its 3 x 3 neighbourhood), N * 9 pairs over the lanes
+    const int npair = N * 9;
+    const FastDiv fd9(9);
+    for (int p0 = 0; p0 < npair; p0 += WAVE) {
+      const int pi = min(p0 + lane, npair - 1);
+      int k, q;
+      fd9.divmod(pi, k, q);
+      const int di = ((q * 11) >> 5) - 1, dj = q - 3 * ((q * 11) >> 5) - 1;  // q / 3 - 1, q % 3 - 1 for q < 9
+      const int ni = L.ncx[k] + di, nj = L.ncy[k] + dj, nu = L.nu[k];
+      const bool nval = (int)(p0 + lane < npair) & (int)(abs(di) <= nu) & (abs(dj) <= nu) & ((unsigned int)ni < (unsigned int)W) &
+                        ((unsigned int)nj < (unsigned int)H);
+      if (nval) g8[ni * H + nj] = g8[ni * H + nj] | 0x80;
     }
     wave_sync_lds();
-    for (int k0 = 0; k0 < N; k0 += WAVE) {
-      const int k = k0 + lane, kc = min(k, N - 1);
-      const bool on = k < N;
-      const int pcx = L.pcx[kc], pcy = L.pcy[kc], pu = L.pu[kc], ncx = L.ncx[kc], ncy = L.ncy[kc], nu = L.nu[kc];
-      const unsigned int pval = on ? block_valid9(pcx, pcy, pu, W, H) : 0u, nval = on ? block_valid9(ncx, ncy, nu, W, H) : 0u;
-      unsigned char pv[9], nv[9];
-#pragma unroll
-      for (int q = 0; q < 9; ++q) {  // clamped (always valid) addresses, all reads in flight together
-        const int di = q / 3 - 1, dj = q % 3 - 1;
-        pv[q] = g8[min(max(pcx + di, 0), W - 1) * H + min(max(pcy + dj, 0), H - 1)];
-        nv[q] = g8[min(max(ncx + di, 0), W - 1) * H + min(max(ncy + dj, 0), H - 1)];
-      }
-      unsigned int pclr = 0, nset = 0;
-#pragma unroll
-      for (int q = 0; q < 9; ++q) {
-        pclr |= (pv[q] == D2D_DYNAMIC) ? (1u << q) : 0u;  // DYNAMIC and unmarked
-        const unsigned char o = nv[q] & 0x7f;
-        nset |= (o != D2D_OCCUPIED && o != D2D_DYNAMIC) ? (1u << q) : 0u;
-      }
-      unsigned int m = pclr & pval;
-      while (m) {
-        const int q = __ffs((int)m) - 1;
-        m &= m - 1;
-        gt[(pcx + q / 3 - 1) * H + (pcy + q % 3 - 1)] = D2D_UNOCCUPIED;
-      }
-      m = nset & nval;
-      while (m) {
-        const int q = __ffs((int)m) - 1;
-        m &= m - 1;
-        gt[(ncx + q / 3 - 1) * H + (ncy + q % 3 - 1)] = D2D_DYNAMIC;
-      }
-      if (on) {
+    for (int p0 = 0; p0 < npair; p0 += WAVE) {
+      const int pi = min(p0 + lane, npair - 1);
+      int k, q;
+      fd9.divmod(pi, k, q);
+      const int di = ((q * 11) >> 5) - 1, dj = q - 3 * ((q * 11) >> 5) - 1;
+      const bool on = p0 + lane < npair;
+      const int pcx = L.pcx[k], pcy = L.pcy[k], pu = L.pu[k], ncx = L.ncx[k], ncy = L.ncy[k], nu = L.nu[k];
+      const int qi = pcx + di, qj = pcy + dj, ni = ncx + di, nj = ncy + dj;
+      const bool pval = (int)on & (int)(abs(di) <= pu) & (int)(abs(dj) <= pu) & ((unsigned int)qi < (unsigned int)W) & ((unsigned int)qj < (unsigned int)H);
+      const bool nval = (int)on & (int)(abs(di) <= nu) & (int)(abs(dj) <= nu) & ((unsigned int)ni < (unsigned int)W) & ((unsigned int)nj < (unsigned int)H);
+      const int pidx = min(max(qi, 0), W - 1) * H + min(max(qj, 0), H - 1), nidx = min(max(ni, 0), W - 1) * H + min(max(nj, 0), H - 1);
+      const unsigned char pv = g8[pidx], nv = g8[nidx] & 0x7f;
+      if (pval & (pv == D2D_DYNAMIC)) gt[pidx] = D2D_UNOCCUPIED;                      // DYNAMIC and unmarked
+      if (nval & (nv != D2D_OCCUPIED) & (nv != D2D_DYNAMIC)) gt[nidx] = D2D_DYNAMIC;
+      if (on & (q == 4)) {  // the centre cell's lane keeps the agent's record
         if (pcx != ncx) prev[3 * k] = ncx;
         if (pcy != ncy) prev[3 * k + 1] = ncy;
         if (pu != nu) prev[3 * k + 2] = nu;
@@ -1119,9 +1102,11 @@ __device__ __forceinline__ void st_collide(const d2d_cfg &c, const d2d_state &s,
   int dead = 0, frz = 0;
   if (col == 0) {
     const double gx = r.x - r.tx, gy = r.y - r.ty;
-    if (sqrt(__builtin_fma(gy, gy, gx * gx)) <= 10.0) r.sm = D2D_SM_GOAL_REACHED;
-    const double vn = sqrt(__builtin_fma(r.vy, r.vy, r.vx * r.vx));
-    dead = (r.fail >= 10 && vn == 0.0) ? 1 : 0;
+    // norm(d) <= 10 (drone_v2.py:223) with numpy's norm = sqrt(fma(dy, dy, dx * dx)): sqrt is correctly rounded and monotone,
+    // and sqrt(s) <= 10 exactly for s <= 0x1.9000000000001p+6 (100 + 1 ulp; checked on the host), so no square root is taken.
+    // norm(v) == 0 (:224) <=> the dot product itself is 0 (sqrt(s) == 0 only for s == 0).
+    if (__builtin_fma(gy, gy, gx * gx) <= 0x1.9000000000001p+6) r.sm = D2D_SM_GOAL_REACHED;
+    dead = (r.fail >= 10 && __builtin_fma(r.vy, r.vy, r.vx * r.vx) == 0.0) ? 1 : 0;
     frz = ((double)r.steps >= c.max_steps && !dead) ? 1 : 0;
   }
   const int done = (col != 0) || dead || frz || (r.sm == D2D_SM_GOAL_REACHED && r.tnext >= r.ntgt);
