@@ -23,7 +23,9 @@ stages' LDS working sets: its step is the fused Drone2DEnv2.step alone (NoMove),
 Besides the headline the line carries, measured after the timed region with HIP events on the launch stream:
   step_kernel    the fused Drone2DEnv2.step kernel alone (k_stages; actions and planner heads resident in HBM)
   raycast_stage  d2d_run_stages(AGENTS | RAYCAST): the raycast kernel the north star's HBM target is quoted on
-(--leg picks one of them for a profiler run: every k_stages row of that trace is then that leg).
+(--leg picks one of them for a profiler run: every k_stages row of that trace is then that leg), and `large_batch`:
+the closed loop, the step kernel and the raycast stage once more on 65 536 envs (--large; the workload's worlds tiled),
+where launch ramp and the tail of slow envs are amortised -- the throughput regime of the same kernels.
 PMC-derived fields (`traffic`, `valu`) come from profiles/pmc_latest.json, which stores them PER ENV-STEP together
 with the launch shape they were measured on; they are scaled to this run's launch and emitted only when workload,
 envs and launch mode match the profile (else null), with `traffic_source` naming the file.
@@ -257,6 +259,32 @@ def stage_leg(torch, clock, env, params, rank, B, stages, K=500, Wm=100):
     return min(reps), reps
 
 
+def large_batch_legs(torch, clock, pkg, vec_env, params, worlds, rank, BL, chunk):
+    """The same three kernels on a batch far above the chip's wave slots (the workload's worlds tiled over it): the closed
+    loop, the fused step and the raycast stage -- measured after the headline, never part of `value`."""
+    nw = len(worlds)
+    tiled = [worlds[i % nw] for i in range(BL)]
+    shape = {'workload': 'config2', 'envs': BL}
+    out = {'envs': BL, 'distinct_worlds': nw}
+    env = vec_env.VecDrone2DEnv(params, BL, device=clock.device, planner='Primitive', worlds=tiled, device_plugins=True, gaze='Oxford')
+    env.closed_loop(300, auto_reset=True)
+    clock.sync()
+    K = 600
+    us = clock.timed_us(lambda: [env.closed_loop(min(chunk, K - c0), auto_reset=True) for c0 in range(0, K, chunk)])
+    algo = algo_bytes(env.cfg, env.state.agent_unit)
+    nl = (K + chunk - 1) // chunk
+    out['closed_loop'] = {'env_steps_per_s': BL * K / (us * 1e-6), 'steps': K, 'prologue_steps': 300,
+                          'roofline': roofline('k_closed', dict(shape, persistent=True), algo, BL, K / nl, us / nl)}
+    us, reps = stage_leg(torch, clock, env, params, rank, BL, 'raycast', K=200, Wm=40)
+    out['raycast_stage'] = {'env_steps_per_s': BL / (us * 1e-6), 'repetitions_us': reps,
+                            'roofline': roofline('raycast_stage', shape, algo_bytes(env.cfg, env.state.agent_unit, 'raycast'), BL, 1, us)}
+    del env
+    env = vec_env.VecDrone2DEnv(params, BL, device=clock.device, planner='external', worlds=tiled)
+    us, reps = stage_leg(torch, clock, env, params, rank, BL, 'step', K=200, Wm=40)
+    out['step_kernel'] = {'env_steps_per_s': BL / (us * 1e-6), 'repetitions_us': reps, 'roofline': roofline('k_stages', shape, algo, BL, 1, us)}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -278,6 +306,9 @@ def main():
     ap.add_argument('--chunk', type=int, default=300, help='steps per persistent d2d_closed_loop launch')
     ap.add_argument('--no-persistent', action='store_true',
                     help='exploration: one launch per stage per step (gaze, perceive, plan, act) instead of the persistent kernel')
+    ap.add_argument('--large', type=int, default=65536,
+                    help='envs of the large-batch legs reported beside the headline (the same kernels where launch ramp and the tail '
+                         'of slow envs are amortised: the throughput regime); 0 = skip')
     ap.add_argument('--distinct-worlds', type=int, default=0,
                     help='build only this many seeded worlds per rank and tile them over the batch (0 = one world per env)')
     args = ap.parse_args()
@@ -444,6 +475,8 @@ def main():
                 'launches': 500, 'repetitions_us': reps, 'env_steps_per_s': B / (us * 1e-6),
                 'roofline': roofline('raycast_stage', sshape, rb, B, 1, us,
                                      {'note': 'bytes: 36 N agents + N hit mask + R S ground-truth reads + R (S - 1) drone-map writes + 44 B pose'})}
+        if args.large and world == 1 and args.leg == 'all' and closed and use_cuda:
+            line['large_batch'] = large_batch_legs(torch, clock, pkg, vec_env, params, worlds, rank, args.large, args.chunk)
         if not args.no_cpu_baseline and world == 1 and args.leg == 'all':
             line['cpu_baseline'] = cpu_baseline(pkg, params, closed)
         print(json.dumps(line), flush=True)

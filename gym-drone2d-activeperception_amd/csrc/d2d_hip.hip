@@ -442,8 +442,9 @@ __device__ __forceinline__ void st_control(const d2d_cfg &c, const StepIn &in, E
 // (agent planes, unit, previous dynamic block, tracker active / len / state) are issued together; the
 // moved agents and the staged tracker data land in LDS for the later stages.  With `move` false the
 // agents are only staged (a launch without the AGENTS stage).
+// `light`: only the collision test / the trackers follow (no rays, no dynamic grid): positions, radii and tracker flags.
 __device__ __forceinline__ void st_agents(const d2d_cfg &c, const d2d_state &s, int e, int lane, const Geom &g,
-                                          const LdsView &L, double inv_scale, bool move, bool want_trk) {
+                                          const LdsView &L, double inv_scale, bool move, bool want_trk, bool light = false) {
   const int N = c.N;
   double *__restrict__ ag = s.agents + (size_t)e * D2D_AF * N;
   const int *__restrict__ prev = s.dyn_prev + (size_t)e * N * 3;
@@ -451,10 +452,21 @@ __device__ __forceinline__ void st_agents(const d2d_cfg &c, const d2d_state &s, 
   for (int k = lane; k < N; k += WAVE) {
     double px = ag[D2D_A_PX * N + k], py = ag[D2D_A_PY * N + k];
     const double velx = ag[D2D_A_VX * N + k], vely = ag[D2D_A_VY * N + k];
-    const double rr = ag[D2D_A_R * N + k], r2 = ag[D2D_A_R2 * N + k];
+    const double rr = ag[D2D_A_R * N + k];
+    const unsigned char act = s.active[(size_t)e * N + k];
+    if (light) {
+      int kl = 1;
+      if (want_trk && c.kf_enabled) kl = s.kf_len[(size_t)e * N + k];
+      L.ax[k] = px;
+      L.ay[k] = py;
+      L.ar[k] = rr;
+      L.act[k] = act;
+      L.klen[k] = kl;
+      continue;
+    }
+    const double r2 = ag[D2D_A_R2 * N + k];
     const int u = s.agent_unit[(size_t)e * N + k];
     const int p0 = prev[3 * k], p1 = prev[3 * k + 1], p2 = prev[3 * k + 2];
-    const unsigned char act = s.active[(size_t)e * N + k];
     int klen = 1;
     if (want_trk && c.kf_enabled) klen = s.kf_len[(size_t)e * N + k];
     if (move) {
@@ -1180,8 +1192,9 @@ __device__ __forceinline__ void run_env(const d2d_cfg &c, const d2d_state &s, in
   unsigned char *__restrict__ dm = s.dmap + (size_t)e * W * H;
 
   // ---------------- batch 1 ----------------
+  const bool gt_staged = FULL && (do_ray || do_dyn);  // the five collision probes alone read global memory directly
   if constexpr (FULL) {
-    if (do_ray || do_dyn || do_col) grid_stage(gt, L.gtw, W * H, lane);
+    if (gt_staged) grid_stage(gt, L.gtw, W * H, lane);
     if (do_obs) grid_stage(dm, L.dmt, W * H, lane);
   }
   StepIn in;
@@ -1194,7 +1207,8 @@ __device__ __forceinline__ void run_env(const d2d_cfg &c, const d2d_state &s, in
   const uint32_t needs_agents = D2D_ST_AGENTS | D2D_ST_RAYCAST | D2D_ST_DYNGRID | D2D_ST_TRACKER | D2D_ST_COLLIDE;
   if (do_trk && c.kf_enabled && g.kf_lds) kf_stage(c, s, e, lane, L);
   if (stages & needs_agents) {
-    st_agents(c, s, e, lane, g, L, inv_scale, (stages & D2D_ST_AGENTS) != 0, do_trk || do_col);
+    st_agents(c, s, e, lane, g, L, inv_scale, (stages & D2D_ST_AGENTS) != 0, do_trk || do_col,
+              !(stages & (D2D_ST_AGENTS | D2D_ST_RAYCAST | D2D_ST_DYNGRID)));
     if (do_trk && !do_ray)  // hit mask of an earlier launch: stage it where the raycast leaves it
       for (int k = lane; k < N; k += WAVE) L.hit[k] = s.hit[(size_t)e * N + k];
     wave_sync_lds();
@@ -1211,6 +1225,15 @@ __device__ __forceinline__ void run_env(const d2d_cfg &c, const d2d_state &s, in
   const bool dyn_fast = do_dyn && N <= WAVE;
   DynCells dc;
   dc.pclr = dc.nfree = 0;
+  if (do_col && lane < 5 && !gt_staged) {  // utils.py:766-771: static cells never change, so the probes can be read now
+    const double R = c.drone_radius;
+    const double ox = (lane == 0) ? -R : (lane == 2 ? R : 0.0);
+    const double oy = (lane == 3) ? -R : (lane == 4 ? R : 0.0);
+    const double qx = r.x + ox, qy = r.y + oy;
+    const bool oob = (qx >= c.W_px || qx < 0.0 || qy >= c.H_px || qy < 0.0);
+    const int pi = min(max(cell_fast(qx, c.scale, inv_scale), 0), W - 1), pj = min(max(cell_fast(qy, c.scale, inv_scale), 0), H - 1);
+    probe_wall = oob || gt[pi * H + pj] == D2D_OCCUPIED;
+  }
   if constexpr (!FULL) {
     if (do_ray && do_obs && wt.cols <= 32 && wt.rows <= 24 && ct.cols <= 33 && ct.rows <= 34) {
       // default geometry (23 x 23 window, 33 x 33 crop): lanes map to (row parity, column), so a cell costs an
@@ -1220,15 +1243,6 @@ __device__ __forceinline__ void run_env(const d2d_cfg &c, const d2d_state &s, in
     } else {
       if (do_ray) tile_load<9>(wt, (unsigned char *)L.gtw, gt, W, H, lane, (unsigned char)D2D_OCCUPIED);
       if (do_obs) tile_load<9>(ct, (unsigned char *)L.dmt, dm, W, H, lane, (unsigned char)0);
-    }
-    if (do_col && lane < 5) {  // utils.py:766-771: static cells never change, so the probes can be read now
-      const double R = c.drone_radius;
-      const double ox = (lane == 0) ? -R : (lane == 2 ? R : 0.0);
-      const double oy = (lane == 3) ? -R : (lane == 4 ? R : 0.0);
-      const double qx = r.x + ox, qy = r.y + oy;
-      const bool oob = (qx >= c.W_px || qx < 0.0 || qy >= c.H_px || qy < 0.0);
-      const int pi = min(max(cell_fast(qx, c.scale, inv_scale), 0), W - 1), pj = min(max(cell_fast(qy, c.scale, inv_scale), 0), H - 1);
-      probe_wall = oob || gt[pi * H + pj] == D2D_OCCUPIED;
     }
     if (do_dyn) dyn_bitmap(c, lane, g, L);
     if (dyn_fast && lane < N) dyn_load(c, gt, lane, L, dc);
@@ -1249,7 +1263,7 @@ __device__ __forceinline__ void run_env(const d2d_cfg &c, const d2d_state &s, in
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     wave_sync_lds();
     if constexpr (FULL) {
-      if (do_col && lane < 5) {  // utils.py:766-771 from the ground-truth copy, BEFORE the dynamic-grid stage marks it
+      if (do_col && lane < 5 && gt_staged) {  // utils.py:766-771 from the ground-truth copy, BEFORE the dynamic-grid stage marks it
         const double R = c.drone_radius;
         const double ox = (lane == 0) ? -R : (lane == 2 ? R : 0.0);
         const double oy = (lane == 3) ? -R : (lane == 4 ? R : 0.0);

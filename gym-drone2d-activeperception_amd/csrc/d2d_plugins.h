@@ -83,7 +83,9 @@ __device__ __forceinline__ int wave_argmin(double t, int idx) {
 
 struct TrkView {  // active trackers of the env, compacted into LDS
   double *mx, *my, *vx, *vy;
-  double *lim_plan, *lim_replan;  // norm(d) <= L rewritten as d.d <= T(L), see sq_threshold
+  double *lim_plan, *lim_replan, *lim_L;  // lim_plan: norm(d) <= L rewritten as d.d <= T(L), see sq_threshold (set by a search);
+                                          // lim_L: replan_check's L = drone_radius + radius, lim_replan: L^2 (1 - 1e-14) -- `norm(d)
+                                          // <= L` is settled by d.d against L^2 (1 -+ 1e-14), the exact square root only in between
   int n;
 };
 
@@ -328,6 +330,7 @@ __device__ int plan_search(const d2d_cfg &c, const d2d_state &s, const d2d_plan 
     // "no candidate" is (+inf, INT_MAX), so a plain lexicographic (cost, slot) compare needs no validity tests.
     double best = kInf;
     int bidx = 0x7fffffff;
+    bool fenced = false;
     {
       // the first D2D_SEARCH_LDS_NODES nodes from their LDS mirror (closed = +inf; an open node with an infinite or
       // NaN cost is told apart by the state plane below, which such a search then falls back to)
@@ -344,6 +347,12 @@ __device__ int plan_search(const d2d_cfg &c, const d2d_state &s, const d2d_plan 
           bidx = take ? si : bidx;
         }
       }
+      // The stores of the previous expansion (node planes, hash table) are drained HERE, not at its end: the scan of the LDS
+      // mirror above does not need them, so it runs while they are in flight.
+      if (nn > nl) {
+        wave_sync_global();
+        fenced = true;
+      }
       for (int s0 = nl; s0 < nn; s0 += WAVE) {  // beyond the mirror: state and cost fetched together
         const int si = s0 + lane;
         const int sc = min(si, nn - 1);
@@ -355,6 +364,7 @@ __device__ int plan_search(const d2d_cfg &c, const d2d_state &s, const d2d_plan 
       }
     }
     bidx = wave_argmin(best, bidx);  // first minimal entry in slot order
+    if (!fenced) wave_sync_global();  // before the state plane, the popped node's fields and the dict probes are read
     if (__builtin_amdgcn_readfirstlane(bidx) == 0x7fffffff) {
       // every open node has a non-finite cost (wild inputs): the literal scan over the state plane decides
       int fb = 0x7fffffff;
@@ -574,7 +584,10 @@ __device__ int plan_search(const d2d_cfg &c, const d2d_state &s, const d2d_plan 
       open_n += nnew;
       SP_T(sp7);
       SP_ADD(6, sp6, sp7);
-      wave_sync_global();  // the next scan / probe reads what the lanes just wrote
+      // a further batch of this expansion probes what this one wrote: full hand-off; after the last batch only the LDS mirror
+      // has to be in order -- the global hand-off waits until the next argmin has scanned it (see there)
+      if (p0 + WAVE < nprim) wave_sync_global();
+      else wave_sync_lds();
       SP_T(sp8);
       SP_ADD(7, sp7, sp8);
       SP_ADD(8, sp0, sp8);
@@ -635,12 +648,12 @@ __device__ int plan_search(const d2d_cfg &c, const d2d_state &s, const d2d_plan 
   return total;
 }
 
-// LDS per wave of k_plan: 6 planes of ncap doubles (active trackers) + the search's hand-off arrays
+// LDS per wave of k_plan: 7 planes of ncap doubles (active trackers) + the search's hand-off arrays
 __host__ __device__ inline int plan_wave_bytes(int N, int nu, int n_sample, int WH) {
   const int ncap = ((N > 0 ? N : 1) + 3) & ~3;
   const int nu4 = (nu + 3) & ~3, ns4 = (2 * n_sample + 3) & ~3;
   const int mapb = WH <= D2D_SEARCH_LDS_MAP ? ((WH + 15) & ~15) : 0;
-  return 6 * 8 * ncap + 8 * (nu4 + ns4) + 8 * 64 + 8 * 64 + 4 * 64 + 128 * 4 + 16 + 8 * D2D_SEARCH_LDS_NODES + mapb;
+  return 7 * 8 * ncap + 8 * (nu4 + ns4) + 8 * 64 + 8 * 64 + 4 * 64 + 128 * 4 + 16 + 8 * D2D_SEARCH_LDS_NODES + mapb;
 }
 
 // replan_check + plan + head waypoint of env e by one wave; `base`: plan_wave_bytes() bytes of LDS
@@ -652,7 +665,8 @@ __device__ __forceinline__ void plan_carve(const d2d_cfg &c, const d2d_plan &p, 
   T.vy = T.vx + ncap;
   T.lim_plan = T.vy + ncap;
   T.lim_replan = T.lim_plan + ncap;
-  S.us = T.lim_replan + ncap;
+  T.lim_L = T.lim_replan + ncap;
+  S.us = T.lim_L + ncap;
   S.st = S.us + ((p.nu + 3) & ~3);
   S.rv = S.st + ((2 * p.n_sample + 3) & ~3);
   S.rk = (long long *)(S.rv + 64);
@@ -722,7 +736,9 @@ __device__ __forceinline__ bool plan_env_quick(const d2d_cfg &c, const d2d_state
       T.mx[q] = m0; T.my[q] = m1; T.vx[q] = m2; T.vy[q] = m3;
       T.lim_plan[q] = c.drone_radius + rad + 5 + c.sigma;  // traj_planner.py:58: the limit itself; only a search needs its
                                                            // squared threshold (plan_env_search), a few percent of the steps
-      T.lim_replan[q] = sq_threshold(c.drone_radius + rad);              // traj_planner.py:228
+      const double Lr = c.drone_radius + rad, L2 = Lr * Lr;               // traj_planner.py:228: norm(...) <= drone_radius + radius
+      T.lim_replan[q] = L2 * (1.0 - 1e-14);
+      T.lim_L[q] = Lr;
     }
     nact += __popcll(am);
   }
@@ -747,16 +763,22 @@ __device__ __forceinline__ bool plan_env_quick(const d2d_cfg &c, const d2d_state
         const int sv = ((int)ti) & 0xff;
         if (in && sv > 0 && dm[min(max(ci, 0), c.W - 1) * c.H + min(max(cj, 0), c.H - 1)] == D2D_OCCUPIED) bad = true;
         for (int q = 0; q < nact; q += 4) {  // four trackers per round, loads first (see plan_is_free)
-          double mx[4], my[4], vx[4], vy[4], lim[4];
+          double mx[4], my[4], vx[4], vy[4], lim[4], lhi[4];
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
             mx[u] = T.mx[q + u]; my[u] = T.my[q + u]; vx[u] = T.vx[q + u]; vy[u] = T.vy[q + u]; lim[u] = T.lim_replan[q + u];
+            lhi[u] = T.lim_L[q + u];
           }
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
             const double ex = mx[u] + ti * vx[u], ey = my[u] + ti * vy[u];
             const double dx = ex - wx, dy = ey - wy;
-            bad = bad | ((q + u < nact) & (__builtin_fma(dy, dy, dx * dx) <= lim[u]));
+            // norm(d) <= L with numpy's norm = sqrt(fma(dy, dy, dx * dx)): settled by d.d against L^2 (1 -+ 1e-14); in between
+            // (never, in practice) the correctly rounded square root decides, as in the reference
+            const double d2 = __builtin_fma(dy, dy, dx * dx);
+            const bool on = q + u < nact;
+            bad = bad | (on & (d2 <= lim[u]));
+            if (on & (d2 > lim[u]) & (d2 <= lhi[u] * lhi[u] * (1.0 + 1e-14))) bad = bad | (sqrt(d2) <= lhi[u]);
           }
         }
       }

@@ -48,15 +48,35 @@ def _cfg(rng):
 REGRESSION_SEEDS = [106, 121, 289, 290, 541, 611]
 
 
-@pytest.mark.parametrize('seed', list(range(SEED_BASE, SEED_BASE + N_SEEDS)) + (REGRESSION_SEEDS if SEED_BASE == 0 else []))
-def test_random_step_matches_oracle(pkg, hip, oracle, seed):
-    rng = np.random.RandomState(7000 + seed)
-    kw = _cfg(rng)
+def _cfg_default_geometry(rng):
+    """The reference's default geometry (utils.py:66-72) with everything else varied: the configurations that take the
+    specialised kernels (both grids staged whole in LDS; N <= 16 / <= 32 / any N), incl. blocks wider than 3 x 3 cells
+    (radius >= 20), label maps, pillars."""
+    kw = dict(agent_number=int(rng.choice([0, 1, 3, 10, 10, 15, 16, 17, 31, 32, 33, 64, 65, 100])),
+              agent_radius=int(rng.choice([-1, 5, 8, 10, 12, 15, 18, 21, 25])),
+              agent_max_speed=int(rng.choice([4, 10, 20, 30, 40, 60])), map_id=int(rng.randint(0, 100000)),
+              pillar_number=int(rng.choice([0, 0, 3, 6, 9])))
+    if rng.rand() < 0.3:
+        kw['static_map'] = str(rng.choice(['maps/obstacle_map.npy', 'maps/shaped_obstacle_map.npy', 'maps/random_map_0.npy']))
+    kw['init_pos'] = [int(rng.randint(40, 460)), int(rng.randint(40, 460))]
+    kw['target_list'] = [[int(rng.randint(40, 460)), int(rng.randint(40, 460))] for _ in range(int(rng.randint(1, 4)))]
+    r = 15 if kw['agent_radius'] == -1 else kw['agent_radius'] + 2
+    while kw['agent_number'] * (2 * r) ** 2 > 0.2 * 460 * 460:
+        kw['agent_number'] //= 2
+    return kw
+
+
+@pytest.mark.parametrize('family,seed', [('any', s) for s in list(range(SEED_BASE, SEED_BASE + N_SEEDS)) +
+                                         (REGRESSION_SEEDS if SEED_BASE == 0 else [])] +
+                         [('default', s) for s in range(SEED_BASE, SEED_BASE + N_SEEDS)])
+def test_random_step_matches_oracle(pkg, hip, oracle, family, seed):
+    rng = np.random.RandomState((7000 if family == 'any' else 57000) + seed)
+    kw = _cfg(rng) if family == 'any' else _cfg_default_geometry(rng)
     B, T = int(rng.choice([2, 5, 9])), 24
     external = bool(rng.rand() < 0.5)
     r2 = np.random.RandomState(900000 + seed)          # drawn apart so that the configurations above keep their seeds
     mode = str(r2.choice(['fused', 'fused', 'split', 'stages']))   # device entry points; the oracle always runs the fused step
-    if r2.rand() < 0.3:
+    if r2.rand() < 0.3 and family == 'any':
         kw['var_cam'] = int(r2.choice([1, 2]))          # measurement noise: the draws are an input (utils.py:605)
     dev, ref = _pair(pkg, hip, oracle, B, planner='Primitive' if external else 'NoMove', **kw)
     W, H = dev.cfg.W_px, dev.cfg.H_px
@@ -90,7 +110,7 @@ def test_random_step_matches_oracle(pkg, hip, oracle, seed):
             for b in range(8):
                 dev.backend.run_stages(dev.cfg, dev._st, 1 << b)
         ref.step(a)
-        _assert_same(dev, ref, f'seed {seed} {kw} external={external} mode={mode} step {t + 1}')
+        _assert_same(dev, ref, f'{family} seed {seed} {kw} external={external} mode={mode} step {t + 1}')
 
 
 N_ROLL = max(8, N_SEEDS // 4)
