@@ -79,6 +79,7 @@ def bind(lib, prefix='d2d_'):
         'closed_loop': (C.c_int, [P(Cfg), P(State), P(Plan), C.c_int32, C.c_int32, P(State), C.c_void_p]),
         'plan_reset': (C.c_int, [P(Cfg), P(Plan), C.c_void_p, C.c_int32, C.c_void_p]),
         'sincos_array': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+        'launch_shape': (C.c_int, [P(Cfg), P(Plan), P(C.c_int32 * 4)]),
     }
     out = {}
     for name, (res, args) in sig.items():
@@ -90,4 +91,4 @@ def bind(lib, prefix='d2d_'):
 
 
 ENTRY_POINTS = ('abi_version', 'last_error', 'step', 'perceive', 'act', 'run_stages', 'rollout', 'reset',
-                'tan_array', 'gaze_stage', 'plan_stage', 'closed_loop', 'plan_reset', 'sincos_array')
+                'tan_array', 'gaze_stage', 'plan_stage', 'closed_loop', 'plan_reset', 'sincos_array', 'launch_shape')

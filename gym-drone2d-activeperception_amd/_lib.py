@@ -13,6 +13,18 @@ class D2DError(RuntimeError):
     pass
 
 
+def launch_shape(cfg, plan=None, fn=None):
+    """(waves per workgroup, LDS bytes per workgroup, workgroups per CU by LDS, specialised kernels?) -- d2d_launch_shape;
+    needs no GPU."""
+    if fn is None:
+        fn = load_library()[1]
+    out = (C.c_int32 * 4)()
+    rc = fn['launch_shape'](C.byref(cfg), None if plan is None else C.byref(plan), C.byref(out))
+    if rc != 0:
+        raise D2DError(f'd2d error {rc}: {fn["last_error"]().decode()}')
+    return tuple(out)
+
+
 def load_library(path=LIB_PATH):
     # torch first: its bundled HIP runtime has to be the one this library binds to.  Loaded the other way round the
     # process ends up with two runtimes and every launch fails with "no ROCm-capable device is detected".

@@ -1964,6 +1964,31 @@ int d2d_closed_loop(const d2d_cfg *c, const d2d_state *s, const d2d_plan *p, int
   return 0;
 }
 
+int d2d_launch_shape(const d2d_cfg *c, const d2d_plan *p, int32_t out[4]) {
+  if (!c || !out) return fail(-1, "launch_shape: null argument");
+  if (c->abi_version != D2D_ABI_VERSION) return fail(-2, "ABI version mismatch");
+  const bool full = spec_path(*c);
+  const int spec = !full ? 0 : (c->N <= spec_ncap(1) ? 1 : (c->N <= spec_ncap(2) ? 2 : 3));
+  int wpb = (spec == 1 || spec == 2) ? WAVES_PER_BLOCK : pick_wpb(*c);
+  size_t wb = 0;
+  if (!p) {
+    wb = wpb ? (size_t)make_geom(*c, wpb, spec_ncap(spec), full).wave_bytes : 0;
+  } else {
+    auto bytes = [&](int w) {
+      return spec == 0 ? closed_wave_bytes<0>(*c, *p, w) : spec == 1 ? closed_wave_bytes<1>(*c, *p, w)
+           : spec == 2 ? closed_wave_bytes<2>(*c, *p, w) : closed_wave_bytes<3>(*c, *p, w);
+    };
+    while (wpb >= 1 && (size_t)bytes(wpb) * wpb > (wpb == 1 ? LDS_HARD : LDS_SOFT)) wpb = (spec == 1 || spec == 2) ? 0 : wpb / 2;
+    wb = wpb >= 1 ? (size_t)bytes(wpb) : 0;
+    if (!p->launch_args || c->planner_mode != D2D_PLANNER_EXTERNAL) wpb = 0;
+  }
+  out[0] = wpb;
+  out[1] = (int32_t)(wb * (size_t)(wpb > 0 ? wpb : 0));
+  out[2] = out[1] > 0 ? (int32_t)(LDS_HARD / (size_t)out[1]) : 0;
+  out[3] = full ? 1 : 0;
+  return 0;
+}
+
 int d2d_sincos_array(const double *in, double *so, double *co, int64_t n, void *stream) {
   if (n < 0 || (n > 0 && (!in || !so || !co))) return fail(-1, "sincos_array: bad arguments");
   if (n == 0) return 0;

@@ -108,21 +108,27 @@ __device__ __forceinline__ double sq_threshold(double L) {
 // tracker's predicted position?  Four trackers per round, loads first: one tracker per iteration pays the LDS latency
 // once per tracker (the trip count is dynamic, the compiler does not pipeline it).  The planes are padded to a multiple
 // of four entries.
-__device__ __forceinline__ bool plan_hits_tracker(const TrkView &T, double x, double y, double t) {
-  bool hit = false;
-  for (int q = 0; q < T.n; q += 4) {
-    double mx[4], my[4], vx[4], vy[4], lim[4];
+template <int WIDTH>
+__device__ __forceinline__ bool plan_hits_round(const TrkView &T, int q, double x, double y, double t) {
+  double mx[WIDTH], my[WIDTH], vx[WIDTH], vy[WIDTH], lim[WIDTH];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      mx[u] = T.mx[q + u]; my[u] = T.my[q + u]; vx[u] = T.vx[q + u]; vy[u] = T.vy[q + u]; lim[u] = T.lim_plan[q + u];
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const double ex = mx[u] + t * vx[u], ey = my[u] + t * vy[u];  // estimate_pos, utils.py:220-223
-      const double dx = x - ex, dy = y - ey;
-      hit = hit | ((q + u < T.n) & (__builtin_fma(dy, dy, dx * dx) <= lim[u]));
-    }
+  for (int u = 0; u < WIDTH; ++u) {
+    mx[u] = T.mx[q + u]; my[u] = T.my[q + u]; vx[u] = T.vx[q + u]; vy[u] = T.vy[q + u]; lim[u] = T.lim_plan[q + u];
   }
+  bool hit = false;
+#pragma unroll
+  for (int u = 0; u < WIDTH; ++u) {
+    const double ex = mx[u] + t * vx[u], ey = my[u] + t * vy[u];  // estimate_pos, utils.py:220-223
+    const double dx = x - ex, dy = y - ey;
+    hit = hit | ((q + u < T.n) & (__builtin_fma(dy, dy, dx * dx) <= lim[u]));
+  }
+  return hit;
+}
+
+__device__ __forceinline__ bool plan_hits_tracker(const TrkView &T, double x, double y, double t) {
+  if (T.n <= 2) return T.n > 0 ? plan_hits_round<2>(T, 0, x, y, t) : false;  // the usual case: one or two active trackers
+  bool hit = false;
+  for (int q = 0; q < T.n; q += 4) hit = hit | plan_hits_round<4>(T, q, x, y, t);
   return hit;
 }
 
@@ -916,6 +922,7 @@ __device__ __forceinline__ CellBox sector_box(double cx, double cy, double depth
   return b;
 }
 
+#define D2D_TOBS_LDS 16
 struct GazeGeom {
   int bbn;    // cells per axis of the bounding box of a view disk
   int ncell;  // bbn * bbn
@@ -929,7 +936,7 @@ __host__ __device__ inline GazeGeom gaze_geom(const d2d_cfg &c, const d2d_plan &
   // int swept index + double reward + candidate bits per box cell, block sums + add stacks per candidate, the plan
   const int sums = 8 * p.n_yaw * (2 * p.pw_nleaf - 1), live = 4 * g.ncell;  // the live-cell list shares the sums' space
   const int bytes = 4 * g.ncell + 8 * g.ncell + ((g.ncell + 7) & ~7) + (((sums > live ? sums : live) + 7) & ~7) + 8 * 16 +
-                    4 * (4 * p.pw_nleaf + p.pw_ntree) + 16;  // + the row range of the cells that carry a non-zero term
+                    4 * (4 * p.pw_nleaf + p.pw_ntree) + 16 + 8 * D2D_TOBS_LDS;  // + row / column masks of the non-zero terms, table head
   g.wave_bytes = (bytes + 15) & ~15;
   return g;
 }
@@ -954,7 +961,8 @@ __device__ __forceinline__ void gaze_env(const d2d_cfg &c, const d2d_state &s, c
   double *lsum = rew + g.ncell;                                   // [n_yaw][nnode]
   const int lsum_doubles = max(p.n_yaw * nnode, (g.ncell + 1) / 2);
   double *stk = lsum + lsum_doubles;                              // [8][2] view directions
-  int *swi = (int *)(stk + 16);                                   // [ncell]
+  double *tobl = stk + 16;                                        // [D2D_TOBS_LDS] head of tobs_tab row 0
+  int *swi = (int *)(tobl + D2D_TOBS_LDS);                        // [ncell]
   int *swl = (int *)lsum;                                         // [ncell] the live cells of the box: done before the sums start
   int *pwl = swi + g.ncell;                                       // [pw_nleaf][4] + [pw_ntree]: the pairwise plan
   int *pwp = pwl + 4 * p.pw_nleaf;
@@ -976,6 +984,7 @@ __device__ __forceinline__ void gaze_env(const d2d_cfg &c, const d2d_state &s, c
     return;
   }
   // the pairwise plan (a few hundred bytes) into LDS with one coalesced read; used only after several barriers
+  if (lane < D2D_TOBS_LDS) tobl[lane] = p.tobs_tab[min(lane, p.tobs_len - 1)];  // the entries below 1 (reward = the value itself)
   for (int k = lane; k < 4 * p.pw_nleaf; k += WAVE) pwl[k] = p.pw_leaf[k];
   for (int k = lane; k < p.pw_ntree; k += WAVE) pwp[k] = p.pw_tree[k];
   const FastDiv fdb(g.bbn);
@@ -1131,7 +1140,16 @@ __device__ __forceinline__ void gaze_env(const d2d_cfg &c, const d2d_state &s, c
     }
     double tobs[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) tobs[u] = sn[u] > 0 ? p.tobs_tab[call - min(sn[u], call)] : p.tobs_tab[p.tobs_len + call];
+    for (int u = 0; u < 4; ++u) {
+      // time since the cell was seen: k calls ago -> 0 + dt + dt + ... (host table).  The reward needs the value itself only
+      // while it is below 1 (the first entries, kept in LDS); a cell never seen starts at 5 (yaw_planner.py:48): stale, reward 1
+      const int k = call - min(sn[u], call);
+      tobs[u] = sn[u] > 0 ? tobl[min(k, D2D_TOBS_LDS - 1)] : 5.0;
+    }
+    if (__any(tobl[D2D_TOBS_LDS - 1] < 1.0)) {  // a time step below 1 / 64: the literal table
+#pragma unroll
+      for (int u = 0; u < 4; ++u) tobs[u] = sn[u] > 0 ? p.tobs_tab[call - min(sn[u], call)] : p.tobs_tab[p.tobs_len + call];
+    }
     unsigned int hr0 = 0, hr1 = 0, hc0 = 0, hc1 = 0;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -1218,17 +1236,15 @@ __device__ __forceinline__ void gaze_env(const d2d_cfg &c, const d2d_state &s, c
   // rows / columns of the grid that hold a non-zero term (they lie inside the box and inside the map)
   const int row_lo = bi + __ffsll((long long)hrows) - 1, row_hi = bi + 63 - __clzll((long long)hrows);
   const int jlo = bj + __ffsll((long long)hcols) - 1, jhi = bj + 64 - __clzll((long long)hcols);
-  int lf_lo = p.pw_rowleaf[row_lo], lf_hi = p.pw_rowleaf[row_hi];  // the blocks those rows can touch: a contiguous range
-  while (lf_hi + 1 < p.pw_nleaf && pwl[4 * (lf_hi + 1)] < (row_hi + 1) * H) ++lf_hi;
   for (int k = lane; k < p.n_yaw * nnode; k += WAVE) lsum[k] = 0.0;  // blocks without a non-zero term sum to 0
-  // the blocks of that range that cover a row with a non-zero term, compacted: lane = block, in order
+  // the blocks that cover a row with a non-zero term, compacted in order: lane = block (their row ranges are in LDS)
   int *hlist = swi;  // the swept map is not needed any more
   int nhl = 0;
-  for (int l0 = lf_lo; l0 <= lf_hi; l0 += WAVE) {
-    const int lf = min(l0 + lane, lf_hi);
+  for (int l0 = 0; l0 < p.pw_nleaf; l0 += WAVE) {
+    const int lf = min(l0 + lane, p.pw_nleaf - 1);
     const int i_first = pwl[4 * lf + 2], i_last = pwl[4 * lf + 3];
-    const int lo = max(i_first - bi, 0), hi = min(i_last - bi, 63);
-    const bool hotl = (l0 + lane <= lf_hi) && lo <= hi && ((hrows >> lo) & ((hi - lo >= 63) ? ~0ull : ((1ull << (hi - lo + 1)) - 1ull))) != 0ull;
+    const int lo = max(max(i_first, row_lo) - bi, 0), hi = min(min(i_last, row_hi) - bi, 63);
+    const bool hotl = (l0 + lane < p.pw_nleaf) && lo <= hi && ((hrows >> lo) & ((hi - lo >= 63) ? ~0ull : ((1ull << (hi - lo + 1)) - 1ull))) != 0ull;
     const unsigned long long hm = __ballot(hotl);
     if (hotl) hlist[nhl + __popcll(hm & ((1ull << lane) - 1ull))] = lf;
     nhl += __popcll(hm);

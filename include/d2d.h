@@ -350,6 +350,13 @@ int d2d_closed_loop(const d2d_cfg *cfg, const d2d_state *st, const d2d_plan *pla
 int d2d_plan_reset(const d2d_cfg *cfg, const d2d_plan *plan, const uint8_t *mask, int32_t mask_stride,
                    void *stream);
 
+/* How the library would launch this configuration (no GPU call; for capacity planning and regression tests): fills
+ * out[0] = waves (envs) per workgroup, out[1] = LDS bytes per workgroup, out[2] = workgroups of that size a CU's 160 KB of
+ * LDS hold, out[3] = 1 if the specialised default-geometry kernels apply (both grids staged whole in LDS), else 0.
+ * `plan` == NULL: the fused step (d2d_step / d2d_run_stages); else the persistent closed loop (d2d_closed_loop), out[0] = 0
+ * when it would fall back to one launch per stage.  Returns 0, or a negative error like every entry point. */
+int d2d_launch_shape(const d2d_cfg *cfg, const d2d_plan *plan, int32_t out[4]);
+
 /* Device restatement of the host libm sin() / cos() the reference's math.sin / math.cos resolve to
  * (yaw_planner.py:71): bit-for-bit glibc 2.35 x86-64 FMA variant for |x| < 105414350.  Test hook. */
 int d2d_sincos_array(const double *in, double *sin_out, double *cos_out, int64_t n, void *stream);

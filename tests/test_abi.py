@@ -111,3 +111,28 @@ def test_header_is_plain_c_for_binders(tmp_path):
     sizes = [int(v) for v in subprocess.check_output([str(exe)]).split()]
     assert sizes == [C.sizeof(A.Cfg), C.sizeof(A.State), C.sizeof(A.Plan)]
     subprocess.check_call(['g++', '-std=c++11', '-Wall', '-Werror', '-I', ROOT, '-x', 'c++', '-fsyntax-only', str(src)])
+
+
+def test_bench_workload_keeps_four_workgroups_per_cu(pkg):
+    """BASELINE config 2 (4096 envs, 10 agents, default geometry): the persistent closed loop launches 4-wave workgroups and a
+    CU's 160 KB of LDS must hold FOUR of them (16 waves per CU = 4096 envs resident on 256 CUs) -- a few hundred bytes more per
+    wave in any phase drop it to three and a quarter of the envs queue behind the others.  d2d_launch_shape needs no GPU."""
+    from drone2d_amd import _lib, host_init, device_plugins
+    import ctypes as C
+    p = pkg.with_defaults(pkg.Params(planner='Primitive', gaze_method='Oxford', agent_number=10, agent_radius=15,
+                                     agent_max_speed=20, drone_max_speed=40, map_id=1))
+    cfg = host_init.derive_cfg(p, B=4096, N=10, T=1, planner_mode=pkg._abi.PLANNER_EXTERNAL, kf_enabled=True)
+    wpb, lds, per_cu, spec = _lib.launch_shape(cfg)
+    assert (wpb, spec) == (4, 1) and per_cu >= 4, (wpb, lds, per_cu)
+    sc, tb = device_plugins.build_tables(p, cfg)
+    plan = pkg._abi.Plan()
+    for k, v in sc.items():
+        setattr(plan, k, v)
+    plan.planner, plan.gaze = pkg._abi.PLAN_PRIMITIVE, pkg._abi.GAZE_OXFORD
+    plan.launch_args = 1                      # any non-null value: the persistent path is chosen (nothing is dereferenced here)
+    wpb, lds, per_cu, spec = _lib.launch_shape(cfg, plan)
+    assert (wpb, spec) == (4, 1) and per_cu >= 4 and lds <= 40960, (wpb, lds, per_cu)
+    # config 3's agent count (172) on the default geometry: one or two waves per workgroup, still the specialised kernels
+    cfg3 = host_init.derive_cfg(p, B=16, N=172, T=1, planner_mode=pkg._abi.PLANNER_EXTERNAL, kf_enabled=True)
+    wpb3, lds3, per_cu3, spec3 = _lib.launch_shape(cfg3)
+    assert wpb3 >= 1 and spec3 == 1 and wpb3 * per_cu3 >= 3
