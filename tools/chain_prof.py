@@ -6,7 +6,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ['D2D_LIB'] = os.path.join(ROOT, 'gym-drone2d-activeperception_amd', 'csrc', 'chainprof.so')
+os.environ.setdefault('D2D_LIB', os.path.join(ROOT, 'gym-drone2d-activeperception_amd', 'csrc', 'chainprof.so'))
 import numpy as np
 import torch
 import drone2d_amd as pkg
