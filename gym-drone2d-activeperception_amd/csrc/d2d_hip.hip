@@ -876,8 +876,8 @@ __device__ __forceinline__ void dyn_full(const d2d_cfg &c, const d2d_state &s, i
   int *prev = s.dyn_prev + (size_t)e * N * 3;
   bool small = true;
   for (int k = lane; k < N; k += WAVE) small = small && (L.pu[k] <= 1 && L.nu[k] <= 1);
-  if (__all(small)) {
-    // blocks of at most 3 x 3 cells: lane = (agent, cell of its 3 x 3 neighbourhood), N * 9 pairs over the lanes
+  if (__all(small) && N * 9 <= 3 * WAVE) {
+    // few agents, blocks of at most 3 x 3 cells: lane = (agent, cell of its 3 x 3 neighbourhood), N * 9 pairs over the lanes
     const int npair = N * 9;
     const FastDiv fd9(9);
     for (int p0 = 0; p0 < npair; p0 += WAVE) {
@@ -906,6 +906,62 @@ __device__ __forceinline__ void dyn_full(const d2d_cfg &c, const d2d_state &s, i
       if (pval & (pv == D2D_DYNAMIC)) gt[pidx] = D2D_UNOCCUPIED;                      // DYNAMIC and unmarked
       if (nval & (nv != D2D_OCCUPIED) & (nv != D2D_DYNAMIC)) gt[nidx] = D2D_DYNAMIC;
       if (on & (q == 4)) {  // the centre cell's lane keeps the agent's record
+        if (pcx != ncx) prev[3 * k] = ncx;
+        if (pcy != ncy) prev[3 * k + 1] = ncy;
+        if (pu != nu) prev[3 * k + 2] = nu;
+      }
+    }
+    return;
+  }
+  if (__all(small)) {
+    // many agents (the lanes are busy with lane = agent): 3 x 3 blocks, fixed trip counts, all reads of a lane in flight together
+    for (int k0 = 0; k0 < N; k0 += WAVE) {
+      const int k = k0 + lane, kc = min(k, N - 1);
+      const bool on = k < N;
+      const int ncx = L.ncx[kc], ncy = L.ncy[kc], nu = L.nu[kc];
+      const unsigned int nval = on ? block_valid9(ncx, ncy, nu, W, H) : 0u;
+#pragma unroll
+      for (int q = 0; q < 9; ++q) {
+        const int di = q / 3 - 1, dj = q % 3 - 1;
+        if ((nval >> q) & 1u) {
+          const int idx = (ncx + di) * H + (ncy + dj);
+          g8[idx] = g8[idx] | 0x80;
+        }
+      }
+    }
+    wave_sync_lds();
+    for (int k0 = 0; k0 < N; k0 += WAVE) {
+      const int k = k0 + lane, kc = min(k, N - 1);
+      const bool on = k < N;
+      const int pcx = L.pcx[kc], pcy = L.pcy[kc], pu = L.pu[kc], ncx = L.ncx[kc], ncy = L.ncy[kc], nu = L.nu[kc];
+      const unsigned int pval = on ? block_valid9(pcx, pcy, pu, W, H) : 0u, nval = on ? block_valid9(ncx, ncy, nu, W, H) : 0u;
+      unsigned char pv[9], nv[9];
+#pragma unroll
+      for (int q = 0; q < 9; ++q) {  // clamped (always valid) addresses, all reads in flight together
+        const int di = q / 3 - 1, dj = q % 3 - 1;
+        pv[q] = g8[min(max(pcx + di, 0), W - 1) * H + min(max(pcy + dj, 0), H - 1)];
+        nv[q] = g8[min(max(ncx + di, 0), W - 1) * H + min(max(ncy + dj, 0), H - 1)];
+      }
+      unsigned int pclr = 0, nset = 0;
+#pragma unroll
+      for (int q = 0; q < 9; ++q) {
+        pclr |= (pv[q] == D2D_DYNAMIC) ? (1u << q) : 0u;  // DYNAMIC and unmarked
+        const unsigned char o = nv[q] & 0x7f;
+        nset |= (o != D2D_OCCUPIED && o != D2D_DYNAMIC) ? (1u << q) : 0u;
+      }
+      unsigned int m = pclr & pval;
+      while (m) {
+        const int q = __ffs((int)m) - 1;
+        m &= m - 1;
+        gt[(pcx + q / 3 - 1) * H + (pcy + q % 3 - 1)] = D2D_UNOCCUPIED;
+      }
+      m = nset & nval;
+      while (m) {
+        const int q = __ffs((int)m) - 1;
+        m &= m - 1;
+        gt[(ncx + q / 3 - 1) * H + (ncy + q % 3 - 1)] = D2D_DYNAMIC;
+      }
+      if (on) {
         if (pcx != ncx) prev[3 * k] = ncx;
         if (pcy != ncy) prev[3 * k + 1] = ncy;
         if (pu != nu) prev[3 * k + 2] = nu;
@@ -1380,6 +1436,11 @@ __device__ __forceinline__ void run_env(const d2d_cfg &c, const d2d_state &s, in
 // SPEC 1: N <= 16 agent slots, SPEC 2: N <= 32 (the default map plus the 14 obstacle_map agents), SPEC 3: the
 // default geometry with any N (LDS capacity and waves per workgroup stay run-time values)
 __host__ __device__ constexpr int spec_ncap(int spec) { return spec == 1 ? 16 : (spec == 2 ? 32 : 0); }
+// Both grids staged whole in LDS (Geom.full) only for the instantiation with few agents (N <= 16: the per-wave working set
+// then stays below 10 KB, four 4-wave workgroups per CU).  With more agents the per-agent planes already fill the LDS and
+// 5 KB more per wave cost occupancy in the persistent loop -- measured on BASELINE config 4 (24 agents): 4.9e7 env-steps/s
+// with whole grids against 5.5e7 with the window / crop tiles; config 3 (172 agents): 8 -> 6 waves per CU, the step 35 % slower.
+__host__ __device__ constexpr bool spec_full(int spec) { return spec == 1; }
 __host__ __device__ inline bool spec_default_matches(const d2d_cfg &c) {
   return c.W == 50 && c.H == 50 && c.R == 50 && c.L == 33 && c.dt == 0.1 && c.scale == 10.0 &&
          c.W_px == 500.0 && c.H_px == 500.0 && c.ray_off0 == -0x1.921fb54442d18p-1 && c.ray_dth == 0x1.015bf9217271ap-5 &&
@@ -1408,7 +1469,7 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK, D2D_MIN_WAVES) void k_stages
   const int e = blockIdx.x * wpb + wv;
   if (e >= c.B) return;
   if ((stages & D2D_ST_SKIP_DONE) && s.flags[(size_t)e * 4 + D2D_F_DONE] != 0) return;
-  const Geom g = make_geom(c, wpb, spec_ncap(SPEC), SPEC != 0);
+  const Geom g = make_geom(c, wpb, spec_ncap(SPEC), spec_full(SPEC));
   const LdsView L = carve(d2d_lds + (size_t)wv * g.wave_bytes, g, c.L);
   EnvRegs r;
 #ifdef D2D_STAMPS
@@ -1423,7 +1484,7 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK, D2D_MIN_WAVES) void k_stages
     r.x = pin[(size_t)e * 2];
     r.y = pin[(size_t)e * 2 + 1];
   }
-  run_env<SPEC != 0>(c, s, e, lane, stages, g, L, s.action[e], r);
+  run_env<spec_full(SPEC)>(c, s, e, lane, stages, g, L, s.action[e], r);
   if (lane == 0) {
     store_regs(s, e, r);
     if (coll_out) coll_out[e] = s.flags[(size_t)e * 4 + D2D_F_COLLISION];
@@ -1521,7 +1582,7 @@ __global__ void k_closed_args(ClosedArgs *dst, d2d_cfg c, d2d_state s, d2d_plan 
 
 template <int SPEC>
 __host__ __device__ inline int closed_wave_bytes(const d2d_cfg &c, const d2d_plan &p, int wpb) {
-  int b = make_geom(c, wpb, spec_ncap(SPEC), SPEC != 0).wave_bytes;
+  int b = make_geom(c, wpb, spec_ncap(SPEC), spec_full(SPEC)).wave_bytes;
   const int pb = plan_wave_bytes(c.N, p.nu, p.n_sample, c.W * c.H), gb = p.gaze == D2D_GAZE_OXFORD ? gaze_geom(c, p).wave_bytes : 0;
   b = b > pb ? b : pb;
   b = b > gb ? b : gb;
@@ -1578,11 +1639,11 @@ __device__ __attribute__((noinline)) void ph_gaze_stages(const ClosedArgs *ap, i
   gaze_env(c, a->s, a->p, a->init, a->on_done == D2D_DONE_RESET, e, lane, base);
   wave_sync_global();
   const int wpb = (SPEC == 1 || SPEC == 2) ? WAVES_PER_BLOCK : (int)(blockDim.x / WAVE);
-  const Geom g = make_geom(c, wpb, spec_ncap(SPEC), SPEC != 0);
+  const Geom g = make_geom(c, wpb, spec_ncap(SPEC), spec_full(SPEC));
   const LdsView L = carve(base, g, c.L);
   EnvRegs r;
   load_regs(a->s, e, r);
-  run_env<SPEC != 0>(c, a->s, e, lane, STAGES, g, L, a->s.action[e], r);
+  run_env<spec_full(SPEC)>(c, a->s, e, lane, STAGES, g, L, a->s.action[e], r);
   if (lane == 0) store_regs(a->s, e, r);
   wave_sync_global();
 }
@@ -1595,11 +1656,11 @@ __device__ __attribute__((noinline)) void ph_stages(const ClosedArgs *ap, int e_
   d2d_cfg c = a->c;
   if (SPEC != 0) spec_default_apply(c);
   const int wpb = (SPEC == 1 || SPEC == 2) ? WAVES_PER_BLOCK : (int)(blockDim.x / WAVE);
-  const Geom g = make_geom(c, wpb, spec_ncap(SPEC), SPEC != 0);
+  const Geom g = make_geom(c, wpb, spec_ncap(SPEC), spec_full(SPEC));
   const LdsView L = carve(base, g, c.L);
   EnvRegs r;
   load_regs(a->s, e, r);
-  run_env<SPEC != 0>(c, a->s, e, lane, STAGES, g, L, a->s.action[e], r);
+  run_env<spec_full(SPEC)>(c, a->s, e, lane, STAGES, g, L, a->s.action[e], r);
   if (lane == 0) store_regs(a->s, e, r);
   wave_sync_global();
 }
@@ -1689,7 +1750,7 @@ bool spec_path(const d2d_cfg &c) {
 
 // envs per workgroup: as many waves as fit the 64 KB budget (4, 2 or 1), one wave with up to 160 KB; 0 = does not fit at all
 int pick_wpb(const d2d_cfg &c) {
-  const bool full = spec_path(c);
+  const bool full = spec_path(c) && spec_full(c.N <= spec_ncap(1) ? 1 : (c.N <= spec_ncap(2) ? 2 : 3));
   for (int wpb = WAVES_PER_BLOCK; wpb >= 1; wpb >>= 1)
     if ((size_t)make_geom(c, wpb, 0, full).wave_bytes * wpb <= LDS_SOFT) return wpb;
   return (size_t)make_geom(c, 1, 0, full).wave_bytes <= LDS_HARD ? 1 : 0;
@@ -1724,14 +1785,14 @@ int launch_stages(const d2d_cfg *c, const d2d_state *s, uint32_t stages, void *s
   if (!st.action) st.action = (const double D2D_AS *)st.drone;  // never dereferenced meaningfully without CONTROL
   if (spec_path(*c) && c->N > spec_ncap(2)) {
     const int wpb = pick_wpb(*c);
-    const Geom g = make_geom(*c, wpb, 0, true);
+    const Geom g = make_geom(*c, wpb, 0, spec_full(3));
     const dim3 grid((c->B + wpb - 1) / wpb), block(WAVE * wpb);
     lds_optin(k_stages<3>, (size_t)g.wave_bytes * wpb);
     hipLaunchKernelGGL(k_stages<3>, grid, block, (size_t)g.wave_bytes * wpb, (hipStream_t)stream, *c, st, stages, pin,
                        coll_out);
   } else if (spec_path(*c)) {
     const int spec = c->N <= spec_ncap(1) ? 1 : 2;
-    const Geom g = make_geom(*c, WAVES_PER_BLOCK, spec_ncap(spec), true);
+    const Geom g = make_geom(*c, WAVES_PER_BLOCK, spec_ncap(spec), spec_full(spec));
     const dim3 grid((c->B + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK), block(WAVE * WAVES_PER_BLOCK);
     const size_t lds = (size_t)g.wave_bytes * WAVES_PER_BLOCK;
     if (spec == 1) hipLaunchKernelGGL(k_stages<1>, grid, block, lds, (hipStream_t)stream, *c, st, stages, pin, coll_out);
@@ -1773,7 +1834,7 @@ int plan_check(const d2d_cfg *c, const d2d_state *s, const d2d_plan *p) {
     if (!c->kf_enabled) return fail(-4, "device plugins need the Kalman trackers on the device (kf_enabled)");
   }
   if (p->planner == D2D_PLAN_PRIMITIVE) {
-    if (!p->u_space || !p->sample_t || !p->traj_t || !p->trk_radius || !p->trk_prev || !p->nodes || !p->hash || !p->plan_stat)
+    if (!p->u_space || !p->sample_t || !p->traj_t || !p->trk_radius || !p->trk_prev || !p->trk_lim || !p->nodes || !p->hash || !p->plan_stat)
       return fail(-1, "plan: null planner pointer");
     if (p->hash_cap <= p->node_cap || (p->hash_cap & (p->hash_cap - 1)))
       return fail(-1, "plan: hash_cap must be a power of two > node_cap");
@@ -1967,8 +2028,8 @@ int d2d_closed_loop(const d2d_cfg *c, const d2d_state *s, const d2d_plan *p, int
 int d2d_launch_shape(const d2d_cfg *c, const d2d_plan *p, int32_t out[4]) {
   if (!c || !out) return fail(-1, "launch_shape: null argument");
   if (c->abi_version != D2D_ABI_VERSION) return fail(-2, "ABI version mismatch");
-  const bool full = spec_path(*c);
-  const int spec = !full ? 0 : (c->N <= spec_ncap(1) ? 1 : (c->N <= spec_ncap(2) ? 2 : 3));
+  const int spec = !spec_path(*c) ? 0 : (c->N <= spec_ncap(1) ? 1 : (c->N <= spec_ncap(2) ? 2 : 3));
+  const bool full = spec_full(spec);
   int wpb = (spec == 1 || spec == 2) ? WAVES_PER_BLOCK : pick_wpb(*c);
   size_t wb = 0;
   if (!p) {

@@ -83,9 +83,7 @@ __device__ __forceinline__ int wave_argmin(double t, int idx) {
 
 struct TrkView {  // active trackers of the env, compacted into LDS
   double *mx, *my, *vx, *vy;
-  double *lim_plan, *lim_replan, *lim_L;  // lim_plan: norm(d) <= L rewritten as d.d <= T(L), see sq_threshold (set by a search);
-                                          // lim_L: replan_check's L = drone_radius + radius, lim_replan: L^2 (1 - 1e-14) -- `norm(d)
-                                          // <= L` is settled by d.d against L^2 (1 -+ 1e-14), the exact square root only in between
+  double *lim_plan, *lim_replan;  // norm(d) <= L rewritten as d.d <= T(L), see sq_threshold
   int n;
 };
 
@@ -654,12 +652,12 @@ __device__ int plan_search(const d2d_cfg &c, const d2d_state &s, const d2d_plan 
   return total;
 }
 
-// LDS per wave of k_plan: 7 planes of ncap doubles (active trackers) + the search's hand-off arrays
+// LDS per wave of k_plan: 6 planes of ncap doubles (active trackers) + the search's hand-off arrays
 __host__ __device__ inline int plan_wave_bytes(int N, int nu, int n_sample, int WH) {
   const int ncap = ((N > 0 ? N : 1) + 3) & ~3;
   const int nu4 = (nu + 3) & ~3, ns4 = (2 * n_sample + 3) & ~3;
   const int mapb = WH <= D2D_SEARCH_LDS_MAP ? ((WH + 15) & ~15) : 0;
-  return 7 * 8 * ncap + 8 * (nu4 + ns4) + 8 * 64 + 8 * 64 + 4 * 64 + 128 * 4 + 16 + 8 * D2D_SEARCH_LDS_NODES + mapb;
+  return 6 * 8 * ncap + 8 * (nu4 + ns4) + 8 * 64 + 8 * 64 + 4 * 64 + 128 * 4 + 16 + 8 * D2D_SEARCH_LDS_NODES + mapb;
 }
 
 // replan_check + plan + head waypoint of env e by one wave; `base`: plan_wave_bytes() bytes of LDS
@@ -671,8 +669,7 @@ __device__ __forceinline__ void plan_carve(const d2d_cfg &c, const d2d_plan &p, 
   T.vy = T.vx + ncap;
   T.lim_plan = T.vy + ncap;
   T.lim_replan = T.lim_plan + ncap;
-  T.lim_L = T.lim_replan + ncap;
-  S.us = T.lim_L + ncap;
+  S.us = T.lim_replan + ncap;
   S.st = S.us + ((p.nu + 3) & ~3);
   S.rv = S.st + ((2 * p.n_sample + 3) & ~3);
   S.rk = (long long *)(S.rv + 64);
@@ -721,15 +718,21 @@ __device__ __forceinline__ bool plan_env_quick(const d2d_cfg &c, const d2d_state
   for (int k0 = 0; k0 < N; k0 += WAVE) {
     const int k = k0 + lane;
     bool act = false;
-    double m0 = 0, m1 = 0, m2 = 0, m3 = 0, rad = 0;
+    double m0 = 0, m1 = 0, m2 = 0, m3 = 0, rad = 0, lim2 = 0;
     if (k < N) {
       act = s.active[(size_t)e * N + k] != 0;
       const bool prev = p.trk_prev[(size_t)e * N + k] != 0;
       rad = p.trk_radius[(size_t)e * N + k];
+      lim2 = p.trk_lim[(size_t)e * N + k];
       if (prev && !act) {
         rad = p.agent_radius;
         p.trk_radius[(size_t)e * N + k] = rad;
+        lim2 = 0.0;
       }
+      // replan_check's `norm(d) <= drone_radius + radius` as `d.d <= lim2`: the threshold (three square roots to find) only
+      // changes with the tracker's radius, so it is kept in the plugin state; 0 = not computed for this radius yet
+      if (act && !(lim2 > 0.0)) lim2 = sq_threshold(c.drone_radius + rad);
+      if (lim2 != p.trk_lim[(size_t)e * N + k]) p.trk_lim[(size_t)e * N + k] = lim2;
       if (prev != act) p.trk_prev[(size_t)e * N + k] = act ? 1 : 0;
       if (act) {
         const double *mu = s.kf + ((size_t)e * N + k) * D2D_KF;
@@ -742,9 +745,7 @@ __device__ __forceinline__ bool plan_env_quick(const d2d_cfg &c, const d2d_state
       T.mx[q] = m0; T.my[q] = m1; T.vx[q] = m2; T.vy[q] = m3;
       T.lim_plan[q] = c.drone_radius + rad + 5 + c.sigma;  // traj_planner.py:58: the limit itself; only a search needs its
                                                            // squared threshold (plan_env_search), a few percent of the steps
-      const double Lr = c.drone_radius + rad, L2 = Lr * Lr;               // traj_planner.py:228: norm(...) <= drone_radius + radius
-      T.lim_replan[q] = L2 * (1.0 - 1e-14);
-      T.lim_L[q] = Lr;
+      T.lim_replan[q] = lim2;                                             // traj_planner.py:228, cached threshold (see below)
     }
     nact += __popcll(am);
   }
@@ -769,22 +770,16 @@ __device__ __forceinline__ bool plan_env_quick(const d2d_cfg &c, const d2d_state
         const int sv = ((int)ti) & 0xff;
         if (in && sv > 0 && dm[min(max(ci, 0), c.W - 1) * c.H + min(max(cj, 0), c.H - 1)] == D2D_OCCUPIED) bad = true;
         for (int q = 0; q < nact; q += 4) {  // four trackers per round, loads first (see plan_is_free)
-          double mx[4], my[4], vx[4], vy[4], lim[4], lhi[4];
+          double mx[4], my[4], vx[4], vy[4], lim[4];
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
             mx[u] = T.mx[q + u]; my[u] = T.my[q + u]; vx[u] = T.vx[q + u]; vy[u] = T.vy[q + u]; lim[u] = T.lim_replan[q + u];
-            lhi[u] = T.lim_L[q + u];
           }
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
             const double ex = mx[u] + ti * vx[u], ey = my[u] + ti * vy[u];
             const double dx = ex - wx, dy = ey - wy;
-            // norm(d) <= L with numpy's norm = sqrt(fma(dy, dy, dx * dx)): settled by d.d against L^2 (1 -+ 1e-14); in between
-            // (never, in practice) the correctly rounded square root decides, as in the reference
-            const double d2 = __builtin_fma(dy, dy, dx * dx);
-            const bool on = q + u < nact;
-            bad = bad | (on & (d2 <= lim[u]));
-            if (on & (d2 > lim[u]) & (d2 <= lhi[u] * lhi[u] * (1.0 + 1e-14))) bad = bad | (sqrt(d2) <= lhi[u]);
+            bad = bad | ((q + u < nact) & (__builtin_fma(dy, dy, dx * dx) <= lim[u]));
           }
         }
       }
@@ -889,6 +884,7 @@ __device__ __forceinline__ void plan_reset_env(const d2d_cfg &c, const d2d_plan 
   for (size_t k = lane; k < N; k += WAVE) {
     if (p.trk_radius && p.trk_radius0) p.trk_radius[e * N + k] = p.trk_radius0[e * N + k];
     if (p.trk_prev) p.trk_prev[e * N + k] = 0;
+    if (p.trk_lim) p.trk_lim[e * N + k] = 0.0;
   }
   if (p.seen_step)
     for (size_t i = lane; i < WH; i += WAVE) p.seen_step[e * WH + i] = 0;

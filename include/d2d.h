@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define D2D_ABI_VERSION 5
+#define D2D_ABI_VERSION 6
 
 /* grid cell codes, utils.py:11-16 */
 #define D2D_UNEXPLORED 0
@@ -247,6 +247,9 @@ typedef struct d2d_plan {
   int32_t D2D_AS *traj_hdr;    /* [B][2] index of the head waypoint, number of waypoints stored (len = stored - head) */
   double D2D_AS *trk_radius;   /* [B][N] drone.trackers[k].radius (envs/drone_v2.py:46; back to agent_radius on archive) */
   uint8_t D2D_AS *trk_prev;    /* [B][N] tracker.active as the planner stage last saw it (detects the archive) */
+  double D2D_AS *trk_lim;      /* [B][N] cache kept by the library: the largest s with sqrt(s) <= drone_radius + trk_radius, i.e.
+                           replan_check's `norm(d) <= drone_radius + radius` (traj_planner.py:228) as `d.d <= s`; 0 = not
+                           computed yet (the state of a fresh or reset plugin state) */
   int32_t D2D_AS *seen_step;   /* [B][W][H] Oxford: number of the plan() call that last saw the cell, 0 = never */
   /* ---- scratch of the search (contents meaningless between calls) ---- */
   double D2D_AS *nodes;        /* [B][node_cap * D2D_NODE_F] search nodes; the field order inside an env's block is the

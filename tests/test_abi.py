@@ -135,4 +135,4 @@ def test_bench_workload_keeps_four_workgroups_per_cu(pkg):
     # config 3's agent count (172) on the default geometry: one or two waves per workgroup, still the specialised kernels
     cfg3 = host_init.derive_cfg(p, B=16, N=172, T=1, planner_mode=pkg._abi.PLANNER_EXTERNAL, kf_enabled=True)
     wpb3, lds3, per_cu3, spec3 = _lib.launch_shape(cfg3)
-    assert wpb3 >= 1 and spec3 == 1 and wpb3 * per_cu3 >= 3
+    assert wpb3 >= 1 and spec3 == 0 and wpb3 * per_cu3 >= 6      # many agents: tiles, not whole grids (8 waves per CU at wpb 2)
