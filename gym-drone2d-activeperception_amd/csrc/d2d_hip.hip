@@ -145,7 +145,8 @@ struct Geom {
   int ldw;    // dwords of the crop tile
   int smax;   // samples after which every ray has stopped: sample k is >= k * ss from the drone
   int klo;    // samples 0..klo are < depth from the drone whatever the slope (k * ss * sqrt(2) < depth)
-  int bmw;    // dwords of the per-env cell bitmap kept in LDS (0: grid too large, loop over agents instead)
+  int bmw;    // dwords of the per-env cell bitmap kept in LDS, or (bmhash) slots of the hash set of covered cells
+  int bmhash; // grid too large for a bitmap (above 256 x 256 cells): the covered cells are kept as a hash set of cell indices
   int kf_lds; // tracker state staged in LDS (fits the 64 KB workgroup budget)
   int full;   // both grids staged WHOLE in LDS (the specialised 50 x 50 geometry): gtw / dmt are the full copies, no tiles, no bitmap
   int wave_bytes;
@@ -168,11 +169,17 @@ __host__ __device__ inline Geom make_geom(const d2d_cfg &c, int wpb, int ncap_fi
   g.klo = (int)kl - ((kl == (double)(int)kl) ? 1 : 0);
   if (g.klo < -1) g.klo = -1;
   g.bmw = (c.W * c.H + 31) / 32;
-  if (g.bmw > 2048) g.bmw = 0;  // 8 KB per wave at most (256 x 256 cells)
+  g.bmhash = 0;
+  if (g.bmw > 2048) {  // a bitmap above 8 KB per wave (256 x 256 cells): a hash set instead, >= 16 slots per agent (3 x 3 blocks: load < 0.6)
+    g.bmhash = 1;
+    g.bmw = 64;
+    while (g.bmw < 16 * g.ncap) g.bmw <<= 1;
+  }
   if (full) {  // whole grids: W * H bytes each (rounded to 16), the dynamic-grid coverage marks live in the gt copy itself
     g.wdw = ((c.W * c.H + 15) & ~15) / 4;
     g.ldw = g.wdw;
     g.bmw = 0;
+    g.bmhash = 0;
   }
   const int base = 64 * g.ncap + 32 * g.ncap + 4 * g.bmw + 4 * g.wdw + 4 * g.ldw + 2 * g.ncap;
   g.kf_lds = (c.kf_enabled && ((base + 160 * g.ncap + 15) & ~15) * wpb <= 64 * 1024) ? 1 : 0;
@@ -724,6 +731,17 @@ __device__ __forceinline__ bool dyn_covered_loop(const LdsView &L, int N, int i,
   return cov;
 }
 
+// ... by the new block of an agent whose block is wider than 3 x 3 cells (the hash set of dyn_bitmap holds the others).  The
+// wave-uniform test first: no such agent in the env (the usual case) -> nothing to walk.
+__device__ __forceinline__ bool dyn_covered_wide(const LdsView &L, int N, int i, int j) {
+  bool cov = false;
+  for (int a = 0; a < N; ++a) {
+    const int u = L.nu[a];
+    cov = cov || (u > 1 && abs(i - L.ncx[a]) <= u && abs(j - L.ncy[a]) <= u);
+  }
+  return cov;
+}
+
 // utils.py:527-540, lane = agent.  The reference clears every cell of dynamic_idx (== every DYNAMIC cell,
 // all of which lie in the blocks of dyn_prev) and then marks every agent's new block.  Written here as
 // ONE order-independent pass: the final value of a cell depends only on (static or not, covered by some
@@ -735,11 +753,34 @@ struct DynCells {  // the common case (blocks of at most 3 x 3 cells), reduced t
   unsigned int nfree;  // bit q: new-block cell q is neither static nor already DYNAMIC
 };
 
-__device__ __forceinline__ void dyn_bitmap(const d2d_cfg &c, int lane, const Geom &g, const LdsView &L) {
+// Returns (hash-set mode): does some agent of the env have a block wider than 3 x 3 cells (not in the set)?
+__device__ __forceinline__ bool dyn_bitmap(const d2d_cfg &c, int lane, const Geom &g, const LdsView &L) {
   const int N = c.N, W = c.W, H = c.H;
-  if (g.bmw == 0) return;
+  if (g.bmw == 0) return false;
   for (int w = lane; w < g.bmw; w += WAVE) L.bm[w] = 0u;
   wave_sync_lds();
+  if (g.bmhash) {  // hash set of the covered cells' indices (+ 1: 0 = empty slot), open addressing; blocks wider than 3 x 3 stay out
+    const unsigned int mask = (unsigned int)g.bmw - 1u;
+    bool wide = false;
+    for (int k = lane; k < N; k += WAVE) wide = wide || L.nu[k] > 1;
+    const bool any_wide = __any(wide);
+    for (int k = lane; k < N; k += WAVE) {
+      const int cx = L.ncx[k], cy = L.ncy[k], u = L.nu[k];
+      if (u > 1) continue;  // such an agent's cells are found by the loop over agents (dyn_covered_wide)
+      const int i1 = min(cx + u + 1, W), j1 = min(cy + u + 1, H);
+      for (int i = max(cx - u, 0); i < i1; ++i)
+        for (int j = max(cy - u, 0); j < j1; ++j) {
+          const unsigned int key = (unsigned int)(i * H + j) + 1u;
+          unsigned int h = (key * 0x9E3779B1u) >> 8 & mask;
+          for (int guard = 0; guard < g.bmw; ++guard) {
+            const unsigned int old = atomicCAS(&L.bm[h], 0u, key);
+            if (old == 0u || old == key) break;
+            h = (h + 1u) & mask;
+          }
+        }
+    }
+    return any_wide;
+  }
   for (int k = lane; k < N; k += WAVE) {
     const int cx = L.ncx[k], cy = L.ncy[k], u = L.nu[k];
     const int i1 = min(cx + u + 1, W), j1 = min(cy + u + 1, H);
@@ -749,6 +790,7 @@ __device__ __forceinline__ void dyn_bitmap(const d2d_cfg &c, int lane, const Geo
         atomicOr(&L.bm[bit >> 5], 1u << (bit & 31));
       }
   }
+  return false;
 }
 
 // 3 x 3 cells (bit q = (di + 1) * 3 + (dj + 1)) of a block of half-width u in {0, 1} that lie inside the grid
@@ -809,13 +851,25 @@ __device__ __forceinline__ void dyn_load(const d2d_cfg &c, const unsigned char *
 
 template <bool FAST>
 __device__ __forceinline__ void dyn_apply(const d2d_cfg &c, const d2d_state &s, int e, int k, const Geom &g,
-                                          const LdsView &L, unsigned char *__restrict__ gt, const DynCells &dc) {
+                                          const LdsView &L, unsigned char *__restrict__ gt, const DynCells &dc, bool any_wide) {
   const int N = c.N, W = c.W, H = c.H;
   int *prev = s.dyn_prev + (size_t)e * N * 3;
-  const bool use_bm = g.bmw > 0;
+  const bool use_bm = g.bmw > 0 && !g.bmhash;
   const int pcx = L.pcx[k], pcy = L.pcy[k], pu = L.pu[k], ncx = L.ncx[k], ncy = L.ncy[k], nu = L.nu[k];
   auto covered = [&](int i, int j) {
     const int bit = i * H + j;
+    if (g.bmhash) {
+      const unsigned int mask = (unsigned int)g.bmw - 1u, key = (unsigned int)bit + 1u;
+      unsigned int h = (key * 0x9E3779B1u) >> 8 & mask;
+      bool found = false;
+      for (int guard = 0; guard < g.bmw; ++guard) {
+        const unsigned int v = L.bm[h];
+        if (v == key) found = true;
+        if (v == key || v == 0u) break;
+        h = (h + 1u) & mask;
+      }
+      return found || (any_wide && dyn_covered_wide(L, N, i, j));  // blocks wider than 3 x 3 are not in the set
+    }
     return use_bm ? ((L.bm[bit >> 5] >> (bit & 31)) & 1u) != 0u : dyn_covered_loop(L, N, i, j);
   };
   if (FAST && pu <= 1 && nu <= 1) {
@@ -1277,7 +1331,7 @@ __device__ __forceinline__ void run_env(const d2d_cfg &c, const d2d_state &s, in
   const int edge = (c.L - 1) / 2;
   const Tile wt = make_tile(ocx - g.reach, ocy - g.reach, g.ws, g.ws);
   const Tile ct = make_tile(ncx_d - edge, ncy_d - edge, c.L, c.L);
-  bool probe_wall = false;
+  bool probe_wall = false, any_wide = false;
   const bool dyn_fast = do_dyn && N <= WAVE;
   DynCells dc;
   dc.pclr = dc.nfree = 0;
@@ -1300,7 +1354,7 @@ __device__ __forceinline__ void run_env(const d2d_cfg &c, const d2d_state &s, in
       if (do_ray) tile_load<9>(wt, (unsigned char *)L.gtw, gt, W, H, lane, (unsigned char)D2D_OCCUPIED);
       if (do_obs) tile_load<9>(ct, (unsigned char *)L.dmt, dm, W, H, lane, (unsigned char)0);
     }
-    if (do_dyn) dyn_bitmap(c, lane, g, L);
+    if (do_dyn) any_wide = dyn_bitmap(c, lane, g, L);
     if (dyn_fast && lane < N) dyn_load(c, gt, lane, L, dc);
   }
 
@@ -1404,9 +1458,9 @@ __device__ __forceinline__ void run_env(const d2d_cfg &c, const d2d_state &s, in
     if constexpr (FULL) {
       dyn_full(c, s, e, lane, L, gt);
     } else if (dyn_fast) {
-      if (lane < N) dyn_apply<true>(c, s, e, lane, g, L, gt, dc);
+      if (lane < N) dyn_apply<true>(c, s, e, lane, g, L, gt, dc, any_wide);
     } else {
-      for (int k = lane; k < N; k += WAVE) dyn_apply<false>(c, s, e, k, g, L, gt, dc);
+      for (int k = lane; k < N; k += WAVE) dyn_apply<false>(c, s, e, k, g, L, gt, dc, any_wide);
     }
   }
 #endif
