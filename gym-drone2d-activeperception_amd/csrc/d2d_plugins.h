@@ -1249,41 +1249,46 @@ __device__ __forceinline__ void gaze_env(const d2d_cfg &c, const d2d_state &s, c
   const int nchain = 8 * nhl;
   const int per_row = (min(jhi - jlo, g.bbn) + 7 + 7) >> 3;  // cells of one residue among the columns with a non-zero term, at most
   const int max_span = 127 / H + 2;      // grid rows a block of <= 128 cells can touch
-  for (int c0 = 0; c0 < nchain; c0 += WAVE) {
-    const int ch = c0 + lane;
-    const bool live = ch < nchain;
-    const int lf = hlist[min(ch, nchain - 1) / 8], r_of = lane & 7;
-    const int off = pwl[4 * lf], m = pwl[4 * lf + 1], i_first = pwl[4 * lf + 2], i_last = pwl[4 * lf + 3];
-    const int gend = off + (m - (m & 7));  // the last m % 8 elements of a block are added after its fold
-    double acc[7];
+  // the walk for NA candidates (6 at the reference's yaw space, 7 at most): view bits of candidates >= n_yaw are never set
+  auto walk = [&](auto na_tag) {
+    constexpr int NA = decltype(na_tag)::value;
+    for (int c0 = 0; c0 < nchain; c0 += WAVE) {
+      const int ch = c0 + lane;
+      const bool live = ch < nchain;
+      const int lf = hlist[min(ch, nchain - 1) / 8], r_of = lane & 7;
+      const int off = pwl[4 * lf], m = pwl[4 * lf + 1], i_first = pwl[4 * lf + 2], i_last = pwl[4 * lf + 3];
+      const int gend = off + (m - (m & 7));  // the last m % 8 elements of a block are added after its fold
+      double acc[NA];
 #pragma unroll
-    for (int a = 0; a < 7; ++a) acc[a] = 0.0;
-    // uniform bounds, predicated body: every lane makes the same number of trips
-    const int i_lo = max(i_first, row_lo);
-    // rows to walk: the largest span among the blocks of this pass (wave-uniform), usually 3 of the possible 4
-    const int my_span = live ? min(i_last, row_hi) - i_lo + 1 : 0;
-    int span = 1;
-    for (int k = 2; k <= max_span; ++k) span = __any(my_span >= k) ? k : span;
-    for (int di = 0; di < span; ++di) {
-      const int i = i_lo + di;
-      const bool row_on = live & (i <= min(i_last, row_hi));
-      const int glo = max(off, i * H + jlo), ghi = min(gend, i * H + jhi);
-      const int rowbase = (i - bi) * g.bbn - i * H - bj;  // box index = rowbase + g
-      const int g0 = glo + ((r_of - glo) & 7);
-      for (int k = 0; k < per_row; ++k) {
-        const int gq = g0 + 8 * k;
-        const bool on = row_on & (gq < ghi);
-        const int q = min(max(rowbase + gq, 0), g.ncell - 1);
-        const unsigned int bits = on ? (unsigned int)cm[q] : 0u;
-        const double rw = rew[q];
+      for (int a = 0; a < NA; ++a) acc[a] = 0.0;
+      // uniform bounds, predicated body: every lane makes the same number of trips
+      const int i_lo = max(i_first, row_lo);
+      // rows to walk: the largest span among the blocks of this pass (wave-uniform), usually 3 of the possible 4
+      const int my_span = live ? min(i_last, row_hi) - i_lo + 1 : 0;
+      int span = 1;
+      for (int k = 2; k <= max_span; ++k) span = __any(my_span >= k) ? k : span;
+      for (int di = 0; di < span; ++di) {
+        const int i = i_lo + di;
+        const bool row_on = live & (i <= min(i_last, row_hi));
+        const int glo = max(off, i * H + jlo), ghi = min(gend, i * H + jhi);
+        const int rowbase = (i - bi) * g.bbn - i * H - bj;  // box index = rowbase + g
+        const int g0 = glo + ((r_of - glo) & 7);
+        for (int k = 0; k < per_row; ++k) {
+          const int gq = g0 + 8 * k;
+          const bool on = row_on & (gq < ghi);
+          const int q = min(max(rowbase + gq, 0), g.ncell - 1);
+          const int bits = on ? (int)cm[q] : 0;
+          const long long rwb = __double_as_longlong(rew[q]);
 #pragma unroll
-        for (int a = 0; a < 7; ++a)
-          if (a < p.n_yaw) acc[a] = acc[a] + (((bits >> a) & 1u) ? rw : 0.0);  // + 0.0 changes nothing
+          for (int a = 0; a < NA; ++a) {
+            // the reward where the candidate's view bit is set, else +0.0 (which changes nothing): the bit as a 64-bit mask
+            const long long msk = (long long)((bits << (31 - a)) >> 31);
+            acc[a] = acc[a] + __longlong_as_double(rwb & msk);
+          }
+        }
       }
-    }
 #pragma unroll
-    for (int a = 0; a < 7; ++a) {
-      if (a < p.n_yaw) {  // ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7))
+      for (int a = 0; a < NA; ++a) {  // ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7))
         double v = acc[a] + row_shl_f64<1>(acc[a]);
         v = v + row_shl_f64<2>(v);
         v = v + row_shl_f64<4>(v);
@@ -1296,10 +1301,12 @@ __device__ __forceinline__ void gaze_env(const d2d_cfg &c, const d2d_state &s, c
             if (r >= 0 && r < g.bbn && cc >= 0 && cc < g.bbn && ((cm[r * g.bbn + cc] >> a) & 1)) x = rew[r * g.bbn + cc];
             v += x;
           }
-        if (r_of == 0 && live) lsum[a * nnode + lf] = v;
+        if (r_of == 0 && live && a < p.n_yaw) lsum[a * nnode + lf] = v;
       }
     }
-  }
+  };
+  if (p.n_yaw <= 6) walk(std::integral_constant<int, 6>{});
+  else walk(std::integral_constant<int, 7>{});
   wave_sync_lds();
 #if defined(D2D_GAZE_ABL) && D2D_GAZE_ABL == 5
   if (lane == 0) act[e] = 0.0;

@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Build-container-only sweep (needs /root/reference): N random closed-loop Oxford + Primitive episodes played by the LIVE
+reference (make_golden.py `live` / `live wide`), each replayed through the oracle -- gaze action, plan() result, head waypoint,
+len(trajectory) and the full state of every step -- and the smallest |tracker distance - threshold| any planner test saw
+(oracle diagnostic), which bounds the one documented deviation: Kalman state equal to numpy's LAPACK to 1e-6 only.
+
+  python tests/golden/live_sweep.py 240 [workers]      ->  tests/golden/live_sweep.json (committed: the evidence)
+"""
+import ctypes as C
+import glob
+import json
+import os
+import subprocess
+import sys
+import tempfile
+from concurrent.futures import ProcessPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+
+def chunk(args):
+    seed0, count, wide = args
+    out = tempfile.mkdtemp(prefix='live_sweep_')
+    cmd = [sys.executable, os.path.join(HERE, 'make_golden.py'), 'live', out, str(seed0), str(count)] + (['wide'] if wide else [])
+    subprocess.check_call(cmd, stdout=subprocess.DEVNULL)
+    import drone2d_amd as pkg
+    from oracle_lib import OracleBackend
+    from test_plugins_cpu import _closed_loop
+    ob = OracleBackend()
+    ob.lib.d2d_oracle_debug_min_margin.restype = C.c_double
+    ob.lib.d2d_oracle_debug_min_margin.argtypes = [C.c_int]
+    ob.lib.d2d_oracle_debug_min_margin(1)
+    files = sorted(glob.glob(os.path.join(out, 'live_oxford_*.npz')))
+    steps, bad = 0, []
+    import numpy as np
+    for f in files:
+        try:
+            _closed_loop(pkg, ob, f)
+            steps += len(np.load(f)['t_action'])
+        except AssertionError as ex:
+            bad.append((os.path.basename(f), str(ex)[:200]))
+    margin = ob.lib.d2d_oracle_debug_min_margin(0)
+    import replay
+    kf_dev = replay.Replay.kf_max_dev
+    for f in files:
+        os.remove(f)
+    os.rmdir(out)
+    return dict(seed0=seed0, episodes=len(files), wide=wide, steps=steps, mismatches=bad, min_margin=margin, kf_dev=kf_dev)
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 240
+    workers = int(sys.argv[2]) if len(sys.argv) > 2 else 6
+    per = 10
+    jobs = [(50000 + i * per, per, i % 3 == 2) for i in range((n + per - 1) // per)]
+    with ProcessPoolExecutor(workers) as ex:
+        res = list(ex.map(chunk, jobs))
+    out = dict(episodes=sum(r['episodes'] for r in res), steps=sum(r['steps'] for r in res),
+               wide_family_episodes=sum(r['episodes'] for r in res if r['wide']),
+               mismatches=[m for r in res for m in r['mismatches']],
+               min_tracker_margin_px=min(r['min_margin'] for r in res),
+               kalman_max_abs_deviation=max(r['kf_dev'] for r in res), kalman_test_tolerance=1e-6, seeds=[r['seed0'] for r in res], episodes_per_seed_block=per,
+               note='every step of every episode: gaze action, plan() result, head waypoint, len(trajectory), grids, flags and fp64 '
+                    'state bit for bit (tests/test_plugins_cpu.py::_closed_loop); min_tracker_margin_px = the closest any tracker '
+                    'distance of Planner.is_free / replan_check came to its threshold; kalman_max_abs_deviation = the largest |oracle - reference| '
+                    'over every tracker mean / covariance entry of every step (what the 1e-6 test tolerance allows for)')
+    json.dump(out, open(os.path.join(HERE, 'live_sweep.json'), 'w'), indent=1)
+    print(json.dumps({k: v for k, v in out.items() if k not in ('seeds', 'note')}))
+
+
+if __name__ == '__main__':
+    main()

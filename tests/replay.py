@@ -28,6 +28,8 @@ def params_from(fx, pkg):
 
 
 class Replay:
+    kf_max_dev = 0.0
+
     def __init__(self, pkg, backend, name, kf=True, copies=1):
         from drone2d_amd import host_init, state
         self.A = pkg._abi
@@ -89,6 +91,9 @@ class Replay:
             assert np.array_equal(g('active'), fx['t_active_post'][t]), tag + 'tracker active bits'
             assert np.array_equal(g('kf_len'), fx['t_kf_len'][t]), tag + 'tracker len(ts)'
             kf = g('kf')
+            dev = max(float(np.max(np.abs(kf[:, :4] - fx['t_kf_mu'][t]), initial=0.0)),
+                      float(np.max(np.abs(kf[:, 4:].reshape(-1, 4, 4) - fx['t_kf_sigma'][t]), initial=0.0)))
+            Replay.kf_max_dev = max(Replay.kf_max_dev, dev)   # how far the tracker state really is from numpy's LAPACK
             np.testing.assert_allclose(kf[:, :4], fx['t_kf_mu'][t], rtol=KF_TOL, atol=KF_TOL, err_msg=tag + 'kf mu')
             np.testing.assert_allclose(kf[:, 4:].reshape(-1, 4, 4), fx['t_kf_sigma'][t], rtol=KF_TOL, atol=KF_TOL,
                                        err_msg=tag + 'kf Sigma')
