@@ -1080,7 +1080,7 @@ __device__ __forceinline__ void obs_full(const d2d_cfg &c, const d2d_state &s, i
 // sparse expressions below give the same values as the oracle's dense loops (tests compare bit for bit).
 template <bool KF_LDS>
 __device__ __forceinline__ void st_tracker(const d2d_cfg &c, const d2d_state &s, int e, int lane, const Geom &g,
-                                           const LdsView &L, EnvRegs &r) {
+                                           const LdsView &L, EnvRegs &r, size_t noise_off) {
   const int N = c.N;
   int arch_n = 0, arch_ts = 0;
   for (int k0 = 0; k0 < N; k0 += WAVE) {
@@ -1095,8 +1095,8 @@ __device__ __forceinline__ void st_tracker(const d2d_cfg &c, const d2d_state &s,
         int len = 1;
         double zx = L.ax[k], zy = L.ay[k];
         if (s.noise) {
-          zx = zx + c.sigma * s.noise[((size_t)e * N + k) * 2];
-          zy = zy + c.sigma * s.noise[((size_t)e * N + k) * 2 + 1];
+          zx = zx + c.sigma * s.noise[noise_off + ((size_t)e * N + k) * 2];
+          zy = zy + c.sigma * s.noise[noise_off + ((size_t)e * N + k) * 2 + 1];
         }
         double m0, m1, m2, m3;
         double S[16];
@@ -1293,7 +1293,7 @@ __device__ __forceinline__ void store_regs(const d2d_state &s, int e, const EnvR
 // batch 2 at all: rays, collision probes, the dynamic-grid update and the observation crop read the copies.
 template <bool FULL>
 __device__ __forceinline__ void run_env(const d2d_cfg &c, const d2d_state &s, int e, int lane, uint32_t stages,
-                                        const Geom &g, const LdsView &L, double action, EnvRegs &r) {
+                                        const Geom &g, const LdsView &L, double action, EnvRegs &r, size_t noise_off = 0) {
   const int N = c.N, W = c.W, H = c.H;
   const double inv_scale = 1.0 / c.scale;
   const bool do_ray = stages & D2D_ST_RAYCAST, do_dyn = stages & D2D_ST_DYNGRID, do_trk = stages & D2D_ST_TRACKER;
@@ -1448,8 +1448,8 @@ __device__ __forceinline__ void run_env(const d2d_cfg &c, const d2d_state &s, in
   D2D_STAMP(7);
 #ifndef D2D_ABL_NOTRK
   if (do_trk) {  // two instantiations: a run-time choice between an LDS and a global pointer would become flat loads
-    if (g.kf_lds) st_tracker<true>(c, s, e, lane, g, L, r);
-    else st_tracker<false>(c, s, e, lane, g, L, r);
+    if (g.kf_lds) st_tracker<true>(c, s, e, lane, g, L, r, noise_off);
+    else st_tracker<false>(c, s, e, lane, g, L, r, noise_off);
   }
 #endif
   D2D_STAMP(8);
@@ -1684,9 +1684,10 @@ __device__ __attribute__((noinline)) void ph_plan_search(const ClosedArgs *ap, i
 
 // gaze + the stages that follow it in one call (one set of callee-saved registers, one fence fewer per step)
 template <int SPEC, uint32_t STAGES>
-__device__ __attribute__((noinline)) void ph_gaze_stages(const ClosedArgs *ap, int e_, int lds_off_) {
+__device__ __attribute__((noinline)) void ph_gaze_stages(const ClosedArgs *ap, int e_, int lds_off_, int t_) {
   const ArgsPtr a = uniform_ptr(ap);
   const int e = __builtin_amdgcn_readfirstlane(e_), lane = threadIdx.x & (WAVE - 1);
+  const int tstep = __builtin_amdgcn_readfirstlane(t_);
   char *base = d2d_lds + __builtin_amdgcn_readfirstlane(lds_off_);
   d2d_cfg c = a->c;
   if (SPEC != 0) spec_default_apply(c);
@@ -1697,7 +1698,9 @@ __device__ __attribute__((noinline)) void ph_gaze_stages(const ClosedArgs *ap, i
   const LdsView L = carve(base, g, c.L);
   EnvRegs r;
   load_regs(a->s, e, r);
-  run_env<spec_full(SPEC)>(c, a->s, e, lane, STAGES, g, L, a->s.action[e], r);
+  // this step's row of the measurement noise (d2d_cfg.noise_rows; utils.py:605 draws fresh normals every step)
+  const size_t noise_off = c.noise_rows > 1 ? (size_t)(tstep % c.noise_rows) * c.B * c.N * 2 : 0;
+  run_env<spec_full(SPEC)>(c, a->s, e, lane, STAGES, g, L, a->s.action[e], r, noise_off);
   if (lane == 0) store_regs(a->s, e, r);
   wave_sync_global();
 }
@@ -1747,7 +1750,7 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK, D2D_MIN_WAVES) void k_closed
       // latency-bound, so the three waves it shares the SIMD with give up little.  (+4 % at 4096 envs; thresholds 16-64
       // and levels 1-2 measure the same, level 3 -- the search's own -- less.)
       if (nsearch * 32 > t + 16) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);
-      ph_gaze_stages<SPEC, D2D_ST_PERCEIVE>(a, e, off);
+      ph_gaze_stages<SPEC, D2D_ST_PERCEIVE>(a, e, off, t);
       if (__builtin_amdgcn_readfirstlane(ph_plan_quick<SPEC>(a, e, off))) {
 #ifdef D2D_CHAIN_PROF
         const unsigned long long s0 = __builtin_amdgcn_s_memtime();
@@ -1760,7 +1763,7 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK, D2D_MIN_WAVES) void k_closed
       }
       ph_stages<SPEC, D2D_ST_ACT>(a, e, off);
     } else {
-      ph_gaze_stages<SPEC, D2D_ST_ALL>(a, e, off);
+      ph_gaze_stages<SPEC, D2D_ST_ALL>(a, e, off, t);
     }
   }
 #ifdef D2D_CHAIN_PROF
@@ -1992,6 +1995,7 @@ int d2d_rollout(const d2d_cfg *c, const d2d_state *s, int32_t nsteps, const doub
   for (int32_t t = 0; t < nsteps; ++t) {
     st.action = (const double D2D_AS *)(actions + (size_t)t * c->B);
     if (wp_steps) st.wp = (const double D2D_AS *)(wp_steps + (size_t)t * c->B * 6);
+    if (s->noise && c->noise_rows > 1) st.noise = s->noise + (size_t)(t % c->noise_rows) * c->B * c->N * 2;
     rc = launch_stages(c, &st, D2D_ST_ALL, stream, pin, coll_out ? coll_out + (size_t)t * c->B : nullptr);
     if (rc) return rc;
   }
@@ -2068,11 +2072,13 @@ int d2d_closed_loop(const d2d_cfg *c, const d2d_state *s, const d2d_plan *p, int
   const uint32_t skip = on_done == D2D_DONE_FREEZE ? D2D_ST_SKIP_DONE : 0;
   for (int32_t t = 0; t < nsteps; ++t) {
     if ((rc = gaze_launch(c, s, p, auto_reset ? init : nullptr, skip != 0, stream))) return rc;
+    d2d_state sn = *s;  // this step's row of the measurement noise
+    if (s->noise && c->noise_rows > 1) sn.noise = s->noise + (size_t)(t % c->noise_rows) * c->B * c->N * 2;
     if (split) {
-      if ((rc = launch_stages(c, s, D2D_ST_PERCEIVE | skip, stream))) return rc;
+      if ((rc = launch_stages(c, &sn, D2D_ST_PERCEIVE | skip, stream))) return rc;
       if ((rc = plan_launch(c, s, p, skip != 0, stream))) return rc;
       if ((rc = launch_stages(c, s, D2D_ST_ACT | skip, stream))) return rc;
-    } else if ((rc = launch_stages(c, s, D2D_ST_ALL | skip, stream))) {
+    } else if ((rc = launch_stages(c, &sn, D2D_ST_ALL | skip, stream))) {
       return rc;
     }
   }

@@ -323,6 +323,10 @@ __device__ int plan_search(const d2d_cfg &c, const d2d_state &s, const d2d_plan 
                          c.H_px == floor(c.H_px) && c.W_px >= 1.0 && c.H_px >= 1.0 && p.safe_dist >= 0.0 &&
                          p.safe_dist <= 1048576.0 && p.safe_dist == floor(p.safe_dist);
   const int safe_i = int_walls ? (int)p.safe_dist : 0, wpx_i = int_walls ? (int)c.W_px : 1, hpx_i = int_walls ? (int)c.H_px : 1;
+  bool pend = false;  // a hash insert whose compare-and-swap result has not been looked at yet
+  unsigned int pend_h = 0;
+  int pend_old = 0, pend_val = 0;
+  (void)pend; (void)pend_h; (void)pend_old; (void)pend_val;
   for (;;) {
     itr += 1;
     if (open_n == 0 || itr >= p.max_itr) break;
@@ -413,6 +417,29 @@ __device__ int plan_search(const d2d_cfg &c, const d2d_state &s, const d2d_plan 
       const int myrank = __popcll(vm & lt_mask);
       SP_T(sp3);
       SP_ADD(2, sp2, sp3);
+#ifndef D2D_SEARCH_PLAIN
+      // inserts of the previous batch / expansion whose compare-and-swap lost its bucket to another lane (rare) go on from the
+      // next bucket: the swaps were issued without waiting for their result (below); every probe comes after this point
+      if (__any(pend)) {
+        if (pend && pend_old != 0) {
+          unsigned int hh = (pend_h + 1u) & hmask;
+          for (int guard = 0; guard < p.hash_cap; ++guard) {
+            if (atomicCAS(&tab[hh], 0, pend_val) == 0) break;
+            hh = (hh + 1) & hmask;
+          }
+        }
+        pend = false;
+      }
+      // the successor's dict key does not depend on the collision test: its first bucket is fetched now and arrives while the
+      // samples are tested (LDS only).  End point and key are evaluated again afterwards: two registers live across the samples.
+      unsigned int h0;
+      int sv0;
+      {
+        const double ex0 = rint((px + H * vx) + (H * H) * hx), ey0 = rint((py + H * vy) + (H * H) * hy);
+        h0 = key_hash(node_key(ex0, ey0, vex, vey)) & hmask;
+        sv0 = __hip_atomic_load(&tab[ok ? h0 : 0u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+#endif
       {
         int *plist = chain, *pcnt = chain + WAVE;  // the path buffer is free during the search
         const int nv = __popcll(vm);
@@ -481,8 +508,9 @@ __device__ int plan_search(const d2d_cfg &c, const d2d_state &s, const d2d_plan 
       int slot = -1;
       long long slot_state = 0;  // state and cost of the node found, fetched in the same round trip as its key
       double slot_cost = 0.0;
+#ifdef D2D_SEARCH_PLAIN
+      unsigned int h = key_hash(key) & hmask;
       if (ok) {
-        unsigned int h = key_hash(key) & hmask;
         for (int guard = 0; guard < p.hash_cap; ++guard) {
           const int sv = __hip_atomic_load(&tab[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // written by atomics
           if (sv == 0) break;
@@ -497,6 +525,25 @@ __device__ int plan_search(const d2d_cfg &c, const d2d_state &s, const d2d_plan 
           h = (h + 1) & hmask;
         }
       }
+#else
+      unsigned int h = h0;  // ends at the bucket with the key, or at the empty bucket a new key goes into
+      if (ok) {
+        int sv = sv0;
+        for (int guard = 0; guard < p.hash_cap; ++guard) {
+          if (sv == 0) break;
+          const long long k2 = nd.key[sv - 1], st2 = nd.state[sv - 1];
+          const double c2 = nd.cost[sv - 1];
+          if (k2 == key) {
+            slot = sv - 1;
+            slot_state = st2;
+            slot_cost = c2;
+            break;
+          }
+          h = (h + 1) & hmask;
+          sv = __hip_atomic_load(&tab[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // written by atomics
+        }
+      }
+#endif
       SP_T(sp5);
       SP_ADD(4, sp4, sp5);
       // the successors among themselves (rank order = lane order = generation order): the first lane of a key owns its
@@ -578,11 +625,20 @@ __device__ int plan_search(const d2d_cfg &c, const d2d_state &s, const d2d_plan 
         nd.state[gslot] = 1;
       }
       if (is_leader && !exists) {
-        unsigned int h = key_hash(key) & hmask;
+#ifdef D2D_SEARCH_PLAIN
+        unsigned int hh = key_hash(key) & hmask;
         for (int guard = 0; guard < p.hash_cap; ++guard) {
-          if (atomicCAS(&tab[h], 0, myslot + 1) == 0) break;
-          h = (h + 1) & hmask;
+          if (atomicCAS(&tab[hh], 0, myslot + 1) == 0) break;
+          hh = (hh + 1) & hmask;
         }
+#else
+        // the probe ended at an empty bucket `h`: the swap goes there, and its result is looked at only before the next probe
+        // (top of the next batch): the round trip overlaps the next argmin instead of stalling this expansion
+        pend_h = h;
+        pend_val = myslot + 1;
+        pend_old = atomicCAS(&tab[h], 0, pend_val);
+        pend = true;
+#endif
       }
       nn += nnew;
       open_n += nnew;

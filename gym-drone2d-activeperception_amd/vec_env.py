@@ -112,11 +112,16 @@ class VecDrone2DEnv:
         self.state.wp.copy_(torch.as_tensor(wp, dtype=torch.float64).reshape(self.num_envs, 6))
 
     def set_noise(self, noise):
-        """Standard-normal draws [B, N, 2] for the measurements of this step (utils.py:605); required when
-        var_cam != 0 (the reference takes them from np.random in agent order)."""
-        n = torch.as_tensor(noise, dtype=torch.float64).reshape(self.num_envs, self.cfg.N, 2).to(self.device).contiguous()
+        """Standard-normal draws for the measurements (utils.py:605); required when var_cam != 0 (the reference takes them
+        from np.random in agent order).  [B, N, 2]: the draws of the next step (every step of a multi-step call would reuse
+        them); [T, B, N, 2]: step t of the next rollout() / closed_loop() call draws from row t % T, as the reference draws
+        fresh normals every step."""
+        n = torch.as_tensor(noise, dtype=torch.float64)
+        rows = n.shape[0] if n.dim() == 4 else 1
+        n = n.reshape(rows, self.num_envs, self.cfg.N, 2).to(self.device).contiguous()
         self.state.noise = n
         self._st.noise = n.data_ptr()
+        self.cfg.noise_rows = rows
 
     def step(self, actions):
         """One fused Drone2DEnv2.step for every env.  Returns (obs, reward, done, info) of tensors."""
@@ -147,7 +152,7 @@ class VecDrone2DEnv:
             pin = torch.as_tensor(pin, dtype=torch.float64, device=self.device).contiguous()
         coll = torch.empty((T, self.num_envs), dtype=torch.uint8, device=self.device) if collisions else None
         S = max(1, min(int(streams), self.num_envs))
-        if S == 1 or self.device.type != 'cuda':
+        if S == 1 or self.device.type != 'cuda' or (self.state.noise is not None and self.cfg.noise_rows > 1):
             self.backend.rollout(self.cfg, self._st, T, actions, pin, coll)
             return coll
         # sub-batch i owns envs [lo, hi): its own cfg (B = hi - lo) and state struct (every pointer offset by lo)
@@ -165,7 +170,8 @@ class VecDrone2DEnv:
             for name in A.STATE_FIELDS:
                 t = self.state.noise if name == 'noise' else self.state.t.get(name)
                 base = getattr(self._st, name)
-                setattr(st, name, None if (t is None or not base) else base + lo * t.stride(0) * t.element_size())
+                stride = 0 if t is None else (t.stride(1) if name == 'noise' else t.stride(0))   # noise: [rows][B][N][2]
+                setattr(st, name, None if (t is None or not base) else base + lo * stride * t.element_size())
             # the step-t row of a sub-batch is not contiguous in [T, B]: give each sub-batch its own copies (made on the
             # current stream, like everything the caller queued before this call)
             a_i = actions[:, lo:hi].contiguous()

@@ -132,7 +132,9 @@ typedef struct d2d_cfg {
   int32_t T;           /* capacity of the per-env target list */
   int32_t planner_mode;
   int32_t kf_enabled;  /* 1: Kalman trackers run on device (kf, kf_len must be set) */
-  int32_t reserved0;
+  int32_t noise_rows;  /* rows of d2d_state.noise, each [B][N][2]: step t of a multi-step call (d2d_rollout, d2d_closed_loop)
+                          draws from row t % noise_rows -- the reference draws fresh normals every step (utils.py:605); 0 or 1 =
+                          one row used by every step (single-step entry points always use row 0) */
   int32_t reserved1;
   double dt;           /* params.dt */
   double scale;        /* params.map_scale (x_scale == y_scale, utils.py:500-501) */
@@ -168,7 +170,7 @@ typedef struct d2d_state {
   const uint8_t D2D_AS *plan_ok;  /* [B] planner.plan() result (drone_v2.py:197); NULL under NOMOVE */
   const uint8_t D2D_AS *wp_valid; /* [B] trajectory non-empty at step_pos (utils.py:734); NULL under NOMOVE */
   const double D2D_AS *wp;        /* [B][6] head waypoint: pos(2), vel(2), acc(2) (utils.py:735-738) */
-  const double D2D_AS *noise;     /* [B][N][2] standard normal draws for utils.py:605, or NULL (sigma must be 0) */
+  const double D2D_AS *noise;     /* [noise_rows][B][N][2] standard normal draws for utils.py:605, or NULL (sigma must be 0) */
   /* ---- outputs of this step (written) ---- */
   uint8_t D2D_AS *hit;        /* [B][N] OR over rays of the per-ray hit lists (utils.py:598-599) */
   int32_t D2D_AS *newly;      /* [B] newly_tracked (utils.py:606-607) */

@@ -524,6 +524,7 @@ int d2d_oracle_rollout(const d2d_cfg *c, const d2d_state *s, int32_t nsteps, con
   for (int k = 0; k < nsteps; ++k) {
     t.action = actions + (size_t)k * c->B;
     if (wp_steps) t.wp = wp_steps + (size_t)k * c->B * 6;
+    if (s->noise && c->noise_rows > 1) t.noise = s->noise + (size_t)(k % c->noise_rows) * c->B * c->N * 2;
     if (pin)
       for (int e = 0; e < c->B; ++e) {
         s->drone[(size_t)e * D2D_DF + D2D_D_X] = pin[2 * e];
@@ -1066,7 +1067,9 @@ int d2d_oracle_closed_loop(const d2d_cfg *c, const d2d_state *s, const d2d_plan 
       if (rc) break;
     }
     if ((rc = d2d_oracle_gaze_stage(c, s, p, 0))) break;
-    if ((rc = d2d_oracle_run_stages(c, s, D2D_ST_PERCEIVE | skip, 0))) break;
+    d2d_state sn = *s; /* this step's row of the measurement noise */
+    if (s->noise && c->noise_rows > 1) sn.noise = s->noise + (size_t)(t % c->noise_rows) * c->B * c->N * 2;
+    if ((rc = d2d_oracle_run_stages(c, &sn, D2D_ST_PERCEIVE | skip, 0))) break;
     if ((rc = d2d_oracle_plan_stage(c, s, p, 0))) break;
     if ((rc = d2d_oracle_run_stages(c, s, D2D_ST_ACT | skip, 0))) break;
   }

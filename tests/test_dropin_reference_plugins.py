@@ -168,3 +168,41 @@ def test_reference_lookahead_row(pkg, oracle, ref_modules):
     row = runner.Experiment(p, backend=oracle).run()
     got = np.array([float(v) for v in row[12:]], dtype=np.float64)
     assert np.allclose(got, fx['r1_row'], rtol=0, atol=1e-9, equal_nan=True), (got, fx['r1_row'])
+
+
+def test_measurement_noise_through_the_facade(pkg, oracle, ref_modules):
+    """var_cam != 0: the reference draws np.random.randn(2) per agent the rays hit, in agent order, from the global stream it
+    seeded with map_id (utils.py:603-605, envs/drone_v2.py:80).  The facade keeps that stream, splits the step after the raycast
+    and feeds the draws to the tracker stage: tracker means / covariances and active bits follow the LIVE reference env."""
+    import io
+    import contextlib
+    with contextlib.redirect_stdout(io.StringIO()):
+        from envs.drone_v2 import Drone2DEnv2 as RefEnv      # the reference's env (stubs for gym / pygame from the fixture)
+        import utils as ref_utils
+    from drone2d_amd import env as envmod
+    kw = dict(planner='NoMove', gaze_method='NoControl', agent_number=14, agent_radius=14, agent_max_speed=20, map_id=77,
+              var_cam=2, init_pos=[250, 250])
+    rp = ref_utils.Params(debug=True, **kw)
+    rp.render = False
+    ref = RefEnv(rp)
+    mine = envmod.Drone2DEnv2(pkg.Params(debug=True, **kw), backend=oracle)
+    rng = np.random.RandomState(5)
+    seen = 0
+    for t in range(60):
+        if t % 10 == 0:                       # next to an agent, looking at it: rays hit, trackers start and update
+            a = ref.agents[(3 * t // 10) % len(ref.agents)].position
+            x, y = int(a[0]) + 10, int(a[1]) - 45
+            x, y = min(max(x, 30), 470), min(max(y, 30), 470)
+            ref.drone.x, ref.drone.y = x, y
+            mine.drone.x, mine.drone.y = x, y
+        act = float(rng.uniform(-1, 1))
+        ref.step(act)
+        mine.step(act)
+        for k, tr in enumerate(ref.drone.trackers[:len(ref.agents)]):
+            assert bool(tr.active) == mine.drone.trackers[k].active, (t, k)
+            if tr.active:
+                seen += 1
+                assert np.allclose(tr.mu_upds[-1][:, 0], mine.drone.trackers[k].mu_upds[-1][:, 0], rtol=0, atol=1e-6), (t, k)
+                assert np.allclose(tr.Sigma_upds[-1], mine.drone.trackers[k].Sigma_upds[-1], rtol=0, atol=1e-6), (t, k)
+        assert np.array_equal(ref.map_gt.grid_map, mine.map_gt.grid_map) and ref.tracked_agent == mine.tracked_agent
+    assert seen > 50

@@ -217,6 +217,44 @@ def test_config5_replicas_at_shard_scale(pkg, hip):
     assert int(small.state.hit.sum()) > 0
 
 
+def test_per_step_measurement_noise_rows(pkg, hip, oracle):
+    """var_cam != 0 in multi-step calls: step t draws from row t % T of a [T, B, N, 2] noise tensor (the reference draws fresh
+    normals every step, utils.py:605) -- d2d_rollout and the persistent d2d_closed_loop, device vs oracle, every field."""
+    from drone2d_amd import vec_env
+    rng = np.random.RandomState(11)
+    dev, ref = _pair(pkg, hip, oracle, 5, agent_number=12, agent_radius=12, agent_max_speed=30, map_id=31, var_cam=2,
+                     init_pos=[250, 250])
+    T = 9
+    noise = rng.standard_normal((4, 5, dev.cfg.N, 2))            # 4 rows for 9 steps: rows wrap around
+    acts = rng.uniform(-1, 1, (T, 5))
+    for env in (dev, ref):
+        env.set_noise(noise)
+    # the drones pinned next to an agent of their world, looking at it (yaw 270 looks along +y): rays hit, trackers start
+    ag = ref.state.agents
+    pin = torch.stack([ag[:, 0, 3].floor() + 10.0, ag[:, 1, 3].floor() - 45.0], dim=1).clamp(30.0, 470.0)
+    acts = acts * 0.2
+    cd = dev.rollout(acts, pin=pin, collisions=True)
+    cr = ref.rollout(acts, pin=pin, collisions=True)
+    dev.sync()
+    assert torch.equal(cd.cpu(), cr) and int(ref.state.active.sum()) > 0
+    _assert_same(dev, ref, 'rollout with noise rows')
+    # the same rows are NOT what a single reused row gives (the test would pass trivially otherwise)
+    one = vec_env.VecDrone2DEnv(dev.params, 5, backend=oracle, worlds=_worlds(ref))
+    one.set_noise(noise[0])
+    one.rollout(acts, pin=pin)
+    assert not torch.equal(one.state.kf, ref.state.kf)
+    # closed loop (persistent kernel on the device): Primitive under a constant gaze
+    p = pkg.Params(planner='Primitive', gaze_method='Rotating', agent_number=12, agent_radius=12, agent_max_speed=30, map_id=31,
+                   var_cam=2, init_pos=[250, 250], drone_max_speed=40)
+    r2 = vec_env.VecDrone2DEnv(p, 4, backend=oracle, planner='Primitive', device_plugins=True, gaze='Rotating')
+    d2 = vec_env.VecDrone2DEnv(p, 4, backend=hip, planner='Primitive', device_plugins=True, gaze='Rotating', worlds=_worlds(r2))
+    n2 = rng.standard_normal((7, 4, d2.cfg.N, 2))
+    for env in (d2, r2):
+        env.set_noise(n2)
+        env.closed_loop(25, auto_reset=True)
+    _assert_same(d2, r2, 'closed loop with noise rows')
+
+
 def test_full_size_properties(pkg, hip):
     """BASELINE config 2 size (4096 envs x 10 agents): size-independent properties on the device alone:
     (i) a batch of identical worlds stays identical, (ii) wall cells of gt never change, explored cells only
