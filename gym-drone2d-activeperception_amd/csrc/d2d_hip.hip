@@ -9,15 +9,18 @@
 //                                      ground-truth window the rays can reach is an LDS tile
 //   collision                        : lane = probe / agent, __any / __ballot reduction
 //   observation                      : an LDS tile of the drone's map that the rays patch in place
-// Memory schedule of one env-step -- two batches of loads, then fire-and-forget stores, no fence:
-//   batch 1  everything whose address does not depend on data: pose, counters, inputs, agents, tracker flags;
-//            the tracker states go to LDS by LDS-DMA (global_load_lds_dwordx4, no VGPRs)
-//   batch 2  everything addressed by batch-1 data: ground-truth window tile and drone-map crop tile (byte loads,
-//            all in flight before the first LDS write), dynamic-grid cells, collision probes -- issued together,
-//            the per-ray tan / candidate work runs meanwhile
+// Memory schedule of one env-step, default geometry with N <= 16 (SPEC 1, Geom.full) -- ONE batch of loads, then fire-and-forget
+// stores, no fence:
+//   batch    everything is addressed by the env index alone: pose, counters, inputs, agents, tracker flags; the tracker states
+//            and BOTH 50 x 50 grids go to LDS whole by LDS-DMA (global_load_lds, no VGPRs).  Rays, collision probes, the
+//            dynamic-grid update (coverage marks kept in the ground-truth copy) and the observation crop read the copies;
+//            the per-ray tan / candidate work runs while the DMA is in flight
 //   stores   agents, drone map, grid, trackers, flags, observation
-// What bounds the kernel is instruction issue (~2000 VALU + ~1500 SALU wave-instructions per env-step, fp64
-// heavy) and SGPR pressure, not bytes: see DESIGN.md section 3 for the measurements behind each choice.
+// Other configurations (more agents, other maps) keep two batches: batch 2 = the ground-truth window tile the rays can reach
+// and the drone-map crop tile (byte loads, all in flight before the first LDS write), dynamic-grid cells, collision probes,
+// all addressed by batch-1 data.
+// What bounds the kernel is instruction issue (~1400 VALU + ~950 SALU wave-instructions per env-step at config 2, fp64
+// heavy), not bytes: see DESIGN.md section 3 for the measurements behind each choice.
 // The planner / gaze plugins (d2d_plugins.h) and the persistent closed loop k_closed (every wave loops over the steps
 // of its own env: gaze -> perceive -> plan -> act) follow the step kernel below.
 // There is no dense contraction on this path, hence no MFMA.  Arithmetic is fp64 in the reference's
