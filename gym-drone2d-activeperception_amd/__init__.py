@@ -9,9 +9,9 @@ Layout
   state.py       device-resident batch state
   vec_env.py     VecDrone2DEnv: B envs stepped in lock-step on one GPU
   env.py         Drone2DEnv2: single-env gym facade (gym-2d-perception-v2) over VecDrone2DEnv
-  planners.py    --planner plugin surface (traj_planner.py)
-  gaze.py        --gaze_method plugin surface (yaw_planner.py)
-  batch.py       HostPluginBatch: B episodes with host plugins in lock-step on one device batch
+  planners.py    --planner plugin surface (traj_planner.py): Primitive / NoMove = views of the device stages
+  gaze.py        --gaze_method plugin surface (yaw_planner.py): Oxford = the device stage, NoControl, Rotating
+  device_plugins.py  host tables + per-env state of the device planner / gaze stages (d2d_plan)
   sweeps.py      survivability sweeps (glob_survivability_calculator.py) on d2d_rollout
   runner.py      Experiment: one episode -> the reference's CSV row (experiment.py)
   dist.py        env sharding across GPUs, RCCL gather of episode statistics

@@ -71,7 +71,7 @@ class ExperimentBatch:
         p = with_defaults(params)
         if p.gaze_method not in ('Oxford', 'Rotating', 'NoControl') or p.planner not in ('Primitive', 'NoMove'):
             raise NotImplementedError('ExperimentBatch runs the device plugins: gaze_method Oxford / Rotating / NoControl, planner '
-                                      'Primitive / NoMove (use Experiment / HostPluginBatch for the host plugins)')
+                                      'Primitive / NoMove (use Experiment, one episode at a time, for host plugin classes)')
         if p.gaze_method == 'NoControl':
             p.drone_view_range = 360                                   # experiment.py:28-29
         self.params = p
