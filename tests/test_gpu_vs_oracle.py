@@ -255,6 +255,24 @@ def test_per_step_measurement_noise_rows(pkg, hip, oracle):
     _assert_same(d2, r2, 'closed loop with noise rows')
 
 
+def test_single_wave_above_64k_of_lds(pkg, hip, oracle):
+    """720 agents: the per-env LDS working set (73 KB) is above the 64 KB a workgroup gets by default -- round 1 refused such a
+    configuration (-4); now the wave gets a workgroup of its own with the kernel opted into more dynamic LDS
+    (hipFuncAttributeMaxDynamicSharedMemorySize).  Device vs oracle, every field."""
+    from drone2d_amd import _lib
+    dev, ref = _pair(pkg, hip, oracle, 3, agent_number=720, agent_radius=4, agent_max_speed=20, map_id=2, map_size=[1000, 1000],
+                     init_pos=[500, 500], target_list=[[900, 900]])
+    wpb, lds, per_cu, spec = _lib.launch_shape(dev.cfg)
+    assert wpb == 1 and lds > 64 * 1024 and per_cu >= 2 and spec == 0
+    rng = np.random.RandomState(3)
+    for t in range(4):
+        a = rng.uniform(-1, 1, 3)
+        dev.step(a)
+        ref.step(a)
+        _assert_same(dev, ref, f'720 agents step {t + 1}')
+    assert int(ref.state.hit.sum()) > 0
+
+
 def test_full_size_properties(pkg, hip):
     """BASELINE config 2 size (4096 envs x 10 agents): size-independent properties on the device alone:
     (i) a batch of identical worlds stays identical, (ii) wall cells of gt never change, explored cells only
