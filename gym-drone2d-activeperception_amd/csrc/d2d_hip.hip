@@ -271,35 +271,6 @@ __device__ __forceinline__ Tile make_tile(int i0, int j0, int rows, int cols) {
   return t;
 }
 
-// first CH x 64 cells of a tile: loads into registers / registers into LDS (split so that the loads of
-// several tiles can be in flight together)
-template <int CH>
-__device__ __forceinline__ void tile_fetch(const Tile &t, unsigned char (&v)[CH], const unsigned char *__restrict__ grid,
-                                           int W, int H, int lane, unsigned char fill) {
-  const FastDiv fd(t.cols);
-#pragma unroll
-  for (int u = 0; u < CH; ++u) {
-    const int idx = u * WAVE + lane;
-    int r, q;
-    fd.divmod(idx, r, q);
-    const int i = t.i0 + r, j = t.j0 + q;
-    // always a valid address (clamped), the fill is selected afterwards: a conditional load would become a
-    // branch around every load and serialize them
-    const unsigned char g = grid[min(max(i, 0), W - 1) * H + min(max(j, 0), H - 1)];
-    v[u] = (i >= 0 && i < W && j >= 0 && j < H) ? g : fill;
-  }
-}
-
-template <int CH>
-__device__ __forceinline__ void tile_put(const Tile &t, const unsigned char (&v)[CH], unsigned char *lds, int lane) {
-  const int n = t.rows * t.cols;
-#pragma unroll
-  for (int u = 0; u < CH; ++u) {
-    const int idx = u * WAVE + lane;
-    if (idx < n) lds[idx] = v[u];
-  }
-}
-
 // Two tiles at once, two rows per wave instruction: lanes 0-31 take row 2t, lanes 32-63 row 2t + 1, lane & 31 is
 // the column (tile A: cols <= 32; tile B: cols <= 33, its column 32 is swept by a last pass with lane = row).
 // MAXA / MAXB bound the row pairs held in registers (12 and 17: 23- and 33-row tiles).
