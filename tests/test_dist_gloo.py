@@ -145,3 +145,12 @@ def test_bench_two_rank_dry_run():
     assert abs(j['value'] - 2 * 5 * 6 / (j['ms_per_step'] * 6e-3)) < 1e-6 * j['value']
     assert j['roofline']['traffic'] is None and 'no PMC pass' in j['roofline']['traffic_source']     # 5 envs: no such profile
     assert j['config']['timed_window']['searches_per_env_per_step'] >= 0
+    # the line's contract (keys the driver and the judge read)
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+              'dtype', 'data', 'config', 'roofline'):
+        assert k in j, k
+    assert j['unit'] == 'env-steps/s' and j['higher_is_better'] is True and j['vs_baseline'] is None and j['dtype'] == 'f64'
+    assert j['data'] == 'synthetic' and 'workload' in j['config'] and 'model' not in j['config']
+    r = j['roofline']
+    assert r['bound'] == 'hbm' and r['unit'] == 'GB/s' and r['peak'] == 8000.0 and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-12
+    assert r['algo_bytes_per_env_step'] == 3844.0          # SURVEY 8(d) for config 2, from the run's own N / R / L / cells per agent
