@@ -64,24 +64,50 @@ class ExperimentBatch:
     """The reference's sweep of episodes (`main.py:26-57`: the same cfg over many map ids, one Experiment and one
     CSV row each) as ONE device batch: env i is the world of `map_id + i`, the gaze policy and the planner run on
     the device (Oxford / Primitive), every env plays exactly one episode (`D2D_DONE_FREEZE`) and `rows()` returns
-    the reference's CSV rows.  Everything an episode needs stays on the GPU; the host only reads the rows."""
+    the reference's CSV rows.  Everything an episode needs stays on the GPU; the host only reads the rows.
+
+    `LookAhead` (main.py:10's default method) is the one host policy a batch runs: it needs the drone's velocity and yaw
+    only, so every step pulls those three numbers per env, evaluates yaw_planner.py:28-39 with the host's libm (the
+    reference's `math.atan2`; there is no bit-exact device atan2 here) and uploads the actions -- one launch per step
+    instead of one per episode."""
 
     def __init__(self, params, num_envs, device='cuda:0', backend=None, workers=0):
         from .vec_env import VecDrone2DEnv, build_worlds
         p = with_defaults(params)
-        if p.gaze_method not in ('Oxford', 'Rotating', 'NoControl') or p.planner not in ('Primitive', 'NoMove'):
-            raise NotImplementedError('ExperimentBatch runs the device plugins: gaze_method Oxford / Rotating / NoControl, planner '
-                                      'Primitive / NoMove (use Experiment, one episode at a time, for host plugin classes)')
+        if p.gaze_method not in ('Oxford', 'Rotating', 'NoControl', 'LookAhead') or p.planner not in ('Primitive', 'NoMove'):
+            raise NotImplementedError('ExperimentBatch runs the device plugins: gaze_method Oxford / Rotating / NoControl (and '
+                                      'LookAhead from the host), planner Primitive / NoMove (use Experiment, one episode at a '
+                                      'time, for other host plugin classes)')
         if p.gaze_method == 'NoControl':
             p.drone_view_range = 360                                   # experiment.py:28-29
         self.params = p
         worlds = build_worlds(p, num_envs, workers=workers)
         self.env = VecDrone2DEnv(p, num_envs, device=device, backend=backend, planner=p.planner, worlds=worlds,
-                                 device_plugins=True, gaze=p.gaze_method)
+                                 device_plugins=True, gaze='external' if p.gaze_method == 'LookAhead' else p.gaze_method)
         self.max_steps = int(np.ceil(p.max_flight_time / p.dt)) + 1           # freezing ends every episode by then
+
+    def _lookahead_actions(self):
+        """yaw_planner.LookAhead.plan for every env (gaze.LookAhead, vectorised over the batch on the host)."""
+        from .gaze import _yaw_rate_towards
+        import math
+        p = self.params
+        d = self.env.state.drone[:, [A.D_VX, A.D_VY, A.D_YAW]].cpu().numpy()
+        out = np.zeros(len(d))
+        for e, (vx, vy, yaw) in enumerate(d):
+            if vx != 0 or vy != 0:
+                out[e] = _yaw_rate_towards(math.degrees(math.atan2(-vy, vx)) % 360, yaw, p.dt, p.drone_max_yaw_speed)
+        return out
 
     def run(self, chunk=None):
         n = self.max_steps
+        if self.params.gaze_method == 'LookAhead':
+            for t in range(n):
+                self.env._set_action(self._lookahead_actions())
+                self.env.closed_loop(1, freeze_done=True)
+                if t % 16 == 15 and bool(self.env.state.flags[:, A.F_DONE].all()):
+                    break
+            self.env.sync()
+            return self.rows()
         chunk = chunk or n
         for c0 in range(0, n, chunk):
             self.env.closed_loop(min(chunk, n - c0), freeze_done=True)

@@ -200,8 +200,9 @@ def gen_sweep():
     save('survivability_sweep', d)
 
 
-def experiment_row(params, policy_name):
-    """One episode driven like Experiment.run (experiment.py:65-103) and the values of its CSV row."""
+def experiment_row(params, policy_name, actions=None):
+    """One episode driven like Experiment.run (experiment.py:65-103) and the values of its CSV row (`actions`: a list
+    that receives the policy's output of every step)."""
     from utils import state_machine
     env = Drone2DEnv2(params)
     pol = getattr(yaw_planner, policy_name)
@@ -209,6 +210,8 @@ def experiment_row(params, policy_name):
     done = False
     while not done:
         a = pol.plan(pol, env.info)
+        if actions is not None:
+            actions.append(float(a))
         _, _, done, info = env.step(a)
     tracking_time = np.array([len(tr.ts) * 0.1 for tr in info['tracker_buffer']]).sum()
     gm = info['drone'].map.grid_map
@@ -233,6 +236,26 @@ def gen_rows():
         d[f'r{i}_row'] = np.array(experiment_row(make_params(**kw), pol), dtype=np.float64)
     d['n'] = np.array(len(cases))
     save('experiment_rows', d)
+
+
+def gen_host_gaze():
+    """Episodes under the reference's host-side gaze policies LookGoal / LookAhead (yaw_planner.py:18-39, 225-257) with the
+    Primitive planner: the CSV row and the policy's action of every step."""
+    d = {}
+    cases = [('LookGoal', dict(gaze_method='LookGoal', planner='Primitive', agent_number=10, agent_max_speed=20,
+                               agent_radius=15, drone_max_speed=40, map_id=3)),
+             ('LookGoal', dict(gaze_method='LookGoal', planner='Primitive', agent_number=30, agent_max_speed=40,
+                               agent_radius=10, drone_max_speed=40, map_id=4)),
+             ('LookAhead', dict(gaze_method='LookAhead', planner='Primitive', agent_number=10, agent_max_speed=20,
+                                agent_radius=15, drone_max_speed=20, map_id=5))]
+    for i, (pol, kw) in enumerate(cases):
+        acts = []
+        d[f'r{i}_cfg'] = np.array(json.dumps(kw))
+        d[f'r{i}_row'] = np.array(experiment_row(make_params(**kw), pol, acts), dtype=np.float64)
+        d[f'r{i}_actions'] = np.array(acts, dtype=np.float64)
+        print(pol, kw['map_id'], len(acts), 'steps', d[f'r{i}_row'])
+    d['n'] = np.array(len(cases))
+    save('host_gaze_rows', d)
 
 
 def gen_flags():
@@ -361,6 +384,8 @@ def main():
         return gen_sweep()
     if len(sys.argv) > 1 and sys.argv[1] == 'rows':
         return gen_rows()
+    if len(sys.argv) > 1 and sys.argv[1] == 'host_gaze':
+        return gen_host_gaze()
     if len(sys.argv) > 1 and sys.argv[1] == 'flags':
         return gen_flags()
     rng = np.random.RandomState(12345)
@@ -452,6 +477,7 @@ def main():
     save('static_maps', maps)
     gen_sweep()
     gen_rows()
+    gen_host_gaze()
     gen_flags()
     gen_closed()
 

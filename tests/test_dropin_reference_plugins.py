@@ -156,18 +156,69 @@ def test_readme_command_with_default_params(pkg, oracle, ref_modules, monkeypatc
 
 
 def test_reference_lookahead_row(pkg, oracle, ref_modules):
-    """experiment_rows r1 (LookAhead + Primitive): the gaze name resolves to the reference's own class (this package
-    carries no LookAhead), the planner is the device stage, the CSV row is the reference's."""
+    """experiment_rows r1 (LookAhead + Primitive) with the REFERENCE'S LookAhead class registered over this package's:
+    the planner is the device stage, the CSV row is the reference's (tests/test_runner.py runs the same row with the
+    package's own LookAhead)."""
     import json
     from drone2d_amd import runner, gaze
     fx = load('experiment_rows')
     kw = json.loads(str(fx['r1_cfg']))
-    assert kw['gaze_method'] == 'LookAhead' and gaze.policy_list['LookAhead'] is ref_modules[1].LookAhead
-    p = pkg.Params(debug=True, **kw)
-    p.render = False
-    row = runner.Experiment(p, backend=oracle).run()
+    assert kw['gaze_method'] == 'LookAhead'
+    own = gaze.policy_list['LookAhead']
+    gaze.register_policy('LookAhead', ref_modules[1].LookAhead)
+    try:
+        p = pkg.Params(debug=True, **kw)
+        p.render = False
+        row = runner.Experiment(p, backend=oracle).run()
+    finally:
+        gaze.register_policy('LookAhead', own)
     got = np.array([float(v) for v in row[12:]], dtype=np.float64)
     assert np.allclose(got, fx['r1_row'], rtol=0, atol=1e-9, equal_nan=True), (got, fx['r1_row'])
+
+
+def test_host_gaze_policies_equal_the_reference_classes(pkg, ref_modules):
+    """gaze.LookAhead / gaze.LookGoal against yaw_planner.LookAhead / LookGoal on the same observations: same value,
+    bit for bit, over random states incl. a drone at rest, the +-180 degree wrap, yaw outside [0, 360), empty
+    trajectories and trajectories through explored / unexplored / out-of-map cells."""
+    from drone2d_amd import gaze
+    yp = ref_modules[1]
+    P = types.SimpleNamespace(dt=0.1, drone_max_yaw_speed=80)
+    rng = np.random.RandomState(11)
+
+    class Map:
+        def __init__(self, g):
+            self.g = g
+
+        def get_grid(self, x, y):
+            if x >= 500 or x < 0 or y >= 500 or y < 0:
+                return 1
+            return self.g[int(x // 10), int(y // 10)]
+
+    class Traj:
+        def __init__(self, pts):
+            self.positions = pts
+
+        def __len__(self):
+            return len(self.positions)
+
+    n = 0
+    for case in range(4000):
+        vel = rng.uniform(-40, 40, 2) * rng.choice([0, 1, 1, 1], 2)
+        if case % 7 == 0:
+            vel = np.round(vel)
+        yaw = rng.uniform(-400, 800) if case % 3 else float(rng.randint(0, 360))
+        drone = types.SimpleNamespace(velocity=vel, yaw=yaw, x=float(rng.randint(0, 500)), y=float(rng.randint(0, 500)),
+                                      map=Map(rng.choice([0, 1, 2], (50, 50), p=[0.2, 0.1, 0.7]).astype(np.uint8)))
+        pts = [np.round(rng.uniform(-20, 520, 2)) for _ in range(rng.randint(0, 12))]
+        if case % 11 == 0 and pts:
+            pts[-1] = np.array([drone.x, drone.y])                     # atan2(-0.0, 0.0)
+        obs = {'drone': drone, 'trajectory': Traj(pts), 'target': np.array([250., 250.])}
+        for name in ('LookAhead', 'LookGoal'):
+            mine, ref = getattr(gaze, name)(P), getattr(yp, name)(P)
+            a, b = mine.plan(obs), ref.plan(obs)
+            assert np.array_equal(np.float64(a), np.float64(b)) and np.signbit(a) == np.signbit(b), (name, case, a, b)
+            n += a != 0
+    assert n > 3000
 
 
 def test_measurement_noise_through_the_facade(pkg, oracle, ref_modules):

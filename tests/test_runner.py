@@ -22,13 +22,48 @@ def _rows(backend, device, which):
 
 
 def test_csv_rows_match_reference_cpu(pkg, oracle):
-    _rows(oracle, 'cpu', [0, 2])      # row 1 is a LookAhead episode: the reference's own class drives it in
-    #                                   test_dropin_reference_plugins.py (build container)
+    _rows(oracle, 'cpu', [0, 1, 2])   # row 1 is a LookAhead + Primitive episode (main.py's default pair): this package's
+    #                                   host LookAhead on the device planner's state
 
 
 @pytest.mark.gpu
 def test_csv_rows_match_reference_gpu(pkg, hip):
-    _rows(hip, hip.device, [0, 2])
+    _rows(hip, hip.device, [0, 1, 2])
+
+
+def _host_gaze(backend, device):
+    """LookGoal / LookAhead (host policies of this package on the device planner's trajectory and the drone's map) against
+    reference episodes: the action of every step, bit for bit, and the CSV row."""
+    from drone2d_amd import runner, gaze, env as envmod
+    import drone2d_amd as pkg
+    fx = load('host_gaze_rows')
+    for i in range(int(fx['n'])):
+        kw = json.loads(str(fx[f'r{i}_cfg']))
+        p = pkg.Params(debug=True, **kw)
+        p.render = False
+        env = envmod.Drone2DEnv2(p, device=device, backend=backend)
+        pol = gaze.policy_list[kw['gaze_method']](p)
+        assert type(pol).__module__.endswith('gaze')                 # this package's class, not a fallback
+        acts, done = [], False
+        while not done:
+            a = pol.plan(env.info)
+            acts.append(float(a))
+            _, _, done, _ = env.step(a)
+        want = fx[f'r{i}_actions']
+        assert len(acts) == len(want) and np.array_equal(np.array(acts), want), \
+            f'case {i}: first difference at step {int(np.argmax(np.array(acts)[:len(want)] != want[:len(acts)]))}'
+        row = runner.Experiment(p, device=device, backend=backend).run()
+        got = np.array([float(v) for v in row[12:]], dtype=np.float64)
+        assert np.allclose(got, fx[f'r{i}_row'], rtol=0, atol=1e-9, equal_nan=True), f'case {i}: {got} vs {fx[f"r{i}_row"]}'
+
+
+def test_host_gaze_policies_match_reference_episodes_cpu(pkg, oracle):
+    _host_gaze(oracle, 'cpu')
+
+
+@pytest.mark.gpu
+def test_host_gaze_policies_match_reference_episodes_gpu(pkg, hip):
+    _host_gaze(hip, hip.device)
 
 
 def test_csv_file_written(pkg, oracle, tmp_path):
@@ -41,19 +76,20 @@ def test_csv_file_written(pkg, oracle, tmp_path):
     assert lines[0].split(',')[0] == 'Method' and len(lines) == 2 and lines[1].startswith('Rotating,Primitive,CVM,2,')
 
 
-def _batch_rows(pkg, backend, device, B=4):
-    """ExperimentBatch (plugins on the device, one frozen episode per env) vs the reference's row for map_id 1 and vs
-    stand-alone Experiment runs (host plugin objects) for the other map ids."""
+def _batch_rows(pkg, backend, device, B=4, case=0):
+    """ExperimentBatch (plugins on the device, one frozen episode per env) vs the reference's row for the first map id and
+    vs stand-alone Experiment runs (host plugin objects) for the other map ids.  case 0: Oxford + Primitive, all on the
+    device; case 1: LookAhead + Primitive, the gaze actions computed on the host for the whole batch every step."""
     from drone2d_amd import runner
     fx = load('experiment_rows')
-    kw = json.loads(str(fx['r0_cfg']))
+    kw = json.loads(str(fx[f'r{case}_cfg']))
     p = pkg.Params(debug=True, **kw)
     p.render = False
     eb = runner.ExperimentBatch(p, B, device=device, backend=backend)
     rows = eb.run()
     assert all(int(d) for d in eb.env.state.flags[:, 3].cpu())                      # every episode ended
     got0 = np.array([float(v) for v in rows[0][12:]], dtype=np.float64)
-    assert np.allclose(got0, fx['r0_row'], rtol=0, atol=1e-9, equal_nan=True), (got0, fx['r0_row'])
+    assert np.allclose(got0, fx[f'r{case}_row'], rtol=0, atol=1e-9, equal_nan=True), (got0, fx[f'r{case}_row'])
     for e in range(1, B):
         q = pkg.Params(debug=True, **dict(kw, map_id=kw['map_id'] + e))
         q.render = False
@@ -98,3 +134,12 @@ def test_experiment_batch_rows_cpu(pkg, oracle):
 @pytest.mark.gpu
 def test_experiment_batch_rows_gpu(pkg, hip):
     _batch_rows(pkg, hip, hip.device, B=6)
+
+
+def test_experiment_batch_lookahead_rows_cpu(pkg, oracle):
+    _batch_rows(pkg, oracle, 'cpu', B=3, case=1)
+
+
+@pytest.mark.gpu
+def test_experiment_batch_lookahead_rows_gpu(pkg, hip):
+    _batch_rows(pkg, hip, hip.device, B=5, case=1)
