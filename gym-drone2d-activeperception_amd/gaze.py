@@ -10,11 +10,15 @@ action buffer on the device, `env.step` recognises the token and uploads nothing
 callers that want the number.  `NoControl` and `Rotating` are the reference's constants; `LookAhead` (the method
 main.py:10 and script/train.py:18 select) and `LookGoal` are a dozen scalar operations on what the step already
 mirrors to the host (velocity, yaw; the stored trajectory and the drone's map), so they run here on the host with
-the same libm calls as the reference (`math.atan2`, `math.degrees`, float `%`).  Any other policy (the reference's
-`Owl`, or its `Oxford` as a host object) is a host plugin too: it reads the env through the `info` proxies; names
-this registry does not know resolve through the reference's `yaw_planner` module when that is importable.
+the same libm calls as the reference (`math.atan2`, `math.degrees`, float `%`); so does `Owl` (36 direction scores
+and 20 candidate yaw rates per decision, one decision every 0.8 s).  Any other policy (the reference's `Oxford` as a
+host object, a user's class) is a host plugin too: it reads the env through the `info` proxies; names this registry
+does not know resolve through the reference's `yaw_planner` module when that is importable.
 """
 import math
+
+import numpy as np
+from numpy.linalg import norm
 
 from .planners import _Registry
 
@@ -83,6 +87,89 @@ class LookGoal:
         return _yaw_rate_towards(heading, drone.yaw, self.params.dt, self.params.drone_max_yaw_speed)
 
 
+def _apart(a, b):
+    """Unsigned angle between two directions given in degrees (scalars or arrays), yaw_planner.py:144-149."""
+    d = abs(a % 360 - b % 360)
+    return np.minimum(d, 360 - d)
+
+
+def _owl_unseen(o, theta):
+    """0 inside the field of view, else the product of the angles (radians) to its two edges (`G`, yaw_planner.py:170-174).
+    `o`: the policy object -- an instance, or the class itself under the reference's class-as-instance use."""
+    if _apart(theta, 0) <= o.fov / 2:
+        return 0
+    return math.radians(_apart(theta, o.fov / 2)) * math.radians(_apart(theta, -o.fov / 2))
+
+
+def _owl_refresh(o, drone):
+    """`update_U`, yaw_planner.py:176-182."""
+    moved = drone.velocity * o.dt
+    for i, deg in enumerate(np.arange(0, 360, 10)):
+        along = np.array([math.cos(math.radians(deg)), math.sin(math.radians(deg))])
+        gain = -moved.dot(along) / o.params.drone_view_depth
+        gain += o.IN_VIEW if _apart(deg, -drone.yaw) < o.fov / 2 else o.OUT_OF_VIEW
+        o.score[i] = max(min(o.score[i] + gain, 1), 0)
+
+
+def _owl_score(o, theta):
+    """`U`, yaw_planner.py:184-186: the score of the ten-degree direction nearest to theta."""
+    return o.score[np.argmin(_apart(np.arange(0, 360, 10), theta))]
+
+
+class Owl:
+    """yaw_planner.py:151-222.  Every 0.8 s: refresh the 36 ten-degree direction scores (how recently each direction was in
+    view, shifted by the drone's motion), then pick the yaw rate among 20 candidates whose heading after 0.8 s costs least --
+    weighted sum of: goal direction out of view, flight direction out of view (times speed squared), tracked agents out of
+    view (times speed / distance), the score of the heading itself, and the turn -- and repeat it for the following six steps.
+    The operations and their order are the reference's (NaNs of a drone at rest included: all costs NaN -> the first
+    candidate).  One reference quirk is kept: the j-th ACTIVE tracker's direction is weighted with the state of tracker j
+    (`zip(d_o, trackers)`, :197), whichever tracker that is."""
+    HOLD = 0.8
+    WEIGHTS = np.array([0.2, 0.9, 1, 0.1, 0])
+    IN_VIEW, OUT_OF_VIEW, AGENT_GAIN = 0.4, -0.05, 1
+
+    def __init__(self, params):
+        self.params = params
+        self.dt = self.HOLD
+        top = params.drone_max_yaw_speed
+        self.rates = np.arange(-top, top, top / 10)
+        self.fov = params.drone_view_range
+        self.queue = []
+        self.score = np.zeros(36)
+
+    def plan(self, observation):
+        top = self.params.drone_max_yaw_speed
+        if len(self.queue) != 0:
+            return self.queue.pop() / top
+        drone, target = observation['drone'], observation['target']
+        trackers = drone.trackers
+        with np.errstate(invalid='ignore', divide='ignore'):
+            _owl_refresh(self, drone)
+            here = np.array([drone.x, drone.y])
+            to_goal = math.degrees(math.atan2(target[1] - drone.y, target[0] - drone.x))
+            to_flight = math.degrees(math.atan2(*((drone.velocity / norm(drone.velocity))[::-1])))
+            to_agents = [math.degrees(math.atan2(*((t.mu_upds[-1][:2, 0] - here)[::-1]))) for t in trackers if t.active is True]
+            pull = [self.AGENT_GAIN * norm(t.mu_upds[-1][2:, 0]) / norm(t.mu_upds[-1][:2, 0] - here)
+                    for _, t in zip(to_agents, trackers)]
+            goal_unknown, flight_unknown = 1 - _owl_score(self, to_goal), 1 - _owl_score(self, to_flight)
+            speed2 = norm(drone.velocity / 10) ** 2
+            headings = -(drone.yaw + self.rates * self.dt)
+            terms = np.zeros([headings.shape[0], 5])
+            costs = np.ones_like(headings)
+            for i, heading in enumerate(headings):
+                terms[i, 0] = _owl_unseen(self, heading - to_goal) * goal_unknown
+                terms[i, 1] = speed2 * _owl_unseen(self, heading - to_flight) * flight_unknown
+                for w, d in zip(pull, to_agents):
+                    terms[i, 2] += w * _owl_unseen(self, heading - d)
+                terms[i, 3] = _owl_score(self, heading)
+                terms[i, 4] = abs(math.radians(self.rates[i] * self.dt))
+                costs[i] = np.sum(terms[i, :].dot(self.WEIGHTS))
+            pick = self.rates[np.argmin(costs)]
+        for _ in range(int(self.dt // self.params.dt) - 1):
+            self.queue.append(pick)
+        return pick / top
+
+
 class DeviceAction:
     """The gaze action of one env as it sits in the device's action buffer (written by d2d_gaze_stage)."""
     __slots__ = ('_env', '_stamp', '_value')
@@ -123,7 +210,8 @@ class _PolicyRegistry(_Registry):
     module, what = 'yaw_planner', 'gaze policy'
 
 
-policy_list = _PolicyRegistry(NoControl=NoControl, Rotating=Rotating, Oxford=Oxford, LookAhead=LookAhead, LookGoal=LookGoal)
+policy_list = _PolicyRegistry(NoControl=NoControl, Rotating=Rotating, Oxford=Oxford, LookAhead=LookAhead, LookGoal=LookGoal,
+                              Owl=Owl)
 
 
 def register_policy(name, cls):

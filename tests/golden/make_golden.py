@@ -239,15 +239,21 @@ def gen_rows():
 
 
 def gen_host_gaze():
-    """Episodes under the reference's host-side gaze policies LookGoal / LookAhead (yaw_planner.py:18-39, 225-257) with the
-    Primitive planner: the CSV row and the policy's action of every step."""
+    """Episodes under the reference's host-side gaze policies LookGoal / LookAhead / Owl (yaw_planner.py:18-39, 225-257,
+    151-222) with the Primitive planner: the CSV row and the policy's action of every step."""
     d = {}
     cases = [('LookGoal', dict(gaze_method='LookGoal', planner='Primitive', agent_number=10, agent_max_speed=20,
                                agent_radius=15, drone_max_speed=40, map_id=3)),
              ('LookGoal', dict(gaze_method='LookGoal', planner='Primitive', agent_number=30, agent_max_speed=40,
                                agent_radius=10, drone_max_speed=40, map_id=4)),
              ('LookAhead', dict(gaze_method='LookAhead', planner='Primitive', agent_number=10, agent_max_speed=20,
-                                agent_radius=15, drone_max_speed=20, map_id=5))]
+                                agent_radius=15, drone_max_speed=20, map_id=5)),
+             ('Owl', dict(gaze_method='Owl', planner='Primitive', agent_number=10, agent_max_speed=20, agent_radius=15,
+                          drone_max_speed=40, map_id=1)),
+             ('Owl', dict(gaze_method='Owl', planner='Primitive', agent_number=30, agent_max_speed=40, agent_radius=10,
+                          drone_max_speed=40, map_id=6))]
+    import warnings
+    warnings.simplefilter('ignore')                      # Owl divides by the speed of a drone at rest
     for i, (pol, kw) in enumerate(cases):
         acts = []
         d[f'r{i}_cfg'] = np.array(json.dumps(kw))

@@ -176,6 +176,30 @@ def test_reference_lookahead_row(pkg, oracle, ref_modules):
     assert np.allclose(got, fx['r1_row'], rtol=0, atol=1e-9, equal_nan=True), (got, fx['r1_row'])
 
 
+@pytest.mark.parametrize('case', [0, 3, 4])
+def test_reference_host_gaze_classes_on_this_env(pkg, oracle, ref_modules, case):
+    """The reference's own LookGoal / Owl classes, registered over this package's, read this env through its proxies
+    (trajectory view, map view, tracker views incl. inactive trackers) and reproduce the reference's episodes."""
+    import json
+    import warnings
+    from drone2d_amd import runner, gaze
+    fx = load('host_gaze_rows')
+    kw = json.loads(str(fx[f'r{case}_cfg']))
+    name = kw['gaze_method']
+    own = gaze.policy_list[name]
+    gaze.register_policy(name, getattr(ref_modules[1], name))
+    try:
+        p = pkg.Params(debug=True, **kw)
+        p.render = False
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            row = runner.Experiment(p, backend=oracle).run()
+    finally:
+        gaze.register_policy(name, own)
+    got = np.array([float(v) for v in row[12:]], dtype=np.float64)
+    assert np.allclose(got, fx[f'r{case}_row'], rtol=0, atol=1e-9, equal_nan=True), (got, fx[f'r{case}_row'])
+
+
 def test_host_gaze_policies_equal_the_reference_classes(pkg, ref_modules):
     """gaze.LookAhead / gaze.LookGoal against yaw_planner.LookAhead / LookGoal on the same observations: same value,
     bit for bit, over random states incl. a drone at rest, the +-180 degree wrap, yaw outside [0, 360), empty

@@ -146,7 +146,7 @@ def test_nomove_facade_and_external_mutation(pkg, oracle):
 
 def test_gaze_registry_and_simple_policies(pkg):
     from drone2d_amd import gaze, planners
-    assert set(gaze.policy_list) == {'NoControl', 'Oxford', 'Rotating'}        # device / constant policies
+    assert set(gaze.policy_list) == {'NoControl', 'Oxford', 'Rotating', 'LookAhead', 'LookGoal', 'Owl'}   # device / constant / host policies: experiment.py:12-19's names
     assert set(planners.planner_list) == {'Primitive', 'NoMove'}               # device stages
     p = pkg.Params()
     assert gaze.NoControl(p).plan({}) == 0 and gaze.Rotating(p).plan({}) == 1
@@ -156,7 +156,7 @@ def test_gaze_registry_and_simple_policies(pkg):
         with pytest.raises(KeyError):
             planners.planner_list['MPC']
         with pytest.raises(KeyError):
-            gaze.policy_list['Owl']
+            gaze.policy_list['SomeOtherPolicy']
     with pytest.raises(TypeError):
         planners.Primitive(object(), p)                                        # a device stage, built by the env only
 
