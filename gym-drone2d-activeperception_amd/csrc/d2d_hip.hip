@@ -1306,7 +1306,7 @@ __device__ __forceinline__ void run_env(const d2d_cfg &c, const d2d_state &s, in
   const Tile wt = make_tile(ocx - g.reach, ocy - g.reach, g.ws, g.ws);
   const Tile ct = make_tile(ncx_d - edge, ncy_d - edge, c.L, c.L);
   bool probe_wall = false, any_wide = false;
-  const bool dyn_fast = do_dyn && N <= WAVE;
+  const bool dyn_fast = do_dyn;  // lane = agent, 64 agents per pass: the first pass's cells are fetched early (below), behind the raycast
   DynCells dc;
   dc.pclr = dc.nfree = 0;
   if (do_col && lane < 5 && !gt_staged) {  // utils.py:766-771: static cells never change, so the probes can be read now
@@ -1431,10 +1431,15 @@ __device__ __forceinline__ void run_env(const d2d_cfg &c, const d2d_state &s, in
   if (do_dyn) {
     if constexpr (FULL) {
       dyn_full(c, s, e, lane, L, gt);
-    } else if (dyn_fast) {
-      if (lane < N) dyn_apply<true>(c, s, e, lane, g, L, gt, dc, any_wide);
     } else {
-      for (int k = lane; k < N; k += WAVE) dyn_apply<false>(c, s, e, k, g, L, gt, dc, any_wide);
+      if (lane < N) dyn_apply<true>(c, s, e, lane, g, L, gt, dc, any_wide);
+      // more than 64 agents: every further pass fetches the 18 cells of its 64 agents together (one round trip), then applies.
+      // A later pass may read cells an earlier one has already written: the rule is order-independent (see dyn_apply).
+      for (int k = WAVE + lane; k < N; k += WAVE) {
+        DynCells dk;
+        dyn_load(c, gt, k, L, dk);
+        dyn_apply<true>(c, s, e, k, g, L, gt, dk, any_wide);
+      }
     }
   }
 #endif

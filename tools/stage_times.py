@@ -10,16 +10,20 @@ sys.path.insert(0, ROOT)
 import torch
 import drone2d_amd as pkg
 from drone2d_amd import vec_env, _abi as A
-from bench import synth_plan
+from bench import synth_plan, WORKLOADS
 
 B = int(os.environ.get('B', 4096))
-params = pkg.Params(planner='Primitive', agent_number=int(os.environ.get('N', 10)), agent_radius=15, agent_max_speed=20, map_id=1)
-worlds = vec_env.build_worlds(params, min(B, 512), workers=0)
+wl = os.environ.get('WORKLOAD')          # e.g. WORKLOAD=config5 B=8192: the stages at that configuration's geometry
+if wl:
+    params = pkg.Params(planner='Primitive', drone_max_speed=40, map_id=1, **WORKLOADS[wl][1])
+else:
+    params = pkg.Params(planner='Primitive', agent_number=int(os.environ.get('N', 10)), agent_radius=15, agent_max_speed=20, map_id=1)
+worlds = vec_env.build_worlds(params, min(B, int(os.environ.get('WORLDS', 512))), workers=int(os.environ.get('WORKERS', 0)))
 env = vec_env.VecDrone2DEnv(params, B, planner='external', worlds=[worlds[i % len(worlds)] for i in range(B)])
 T = 260
 g = torch.Generator().manual_seed(1)
 actions = (torch.rand(T, B, generator=g, dtype=torch.float64) * 2 - 1).cuda()
-wp = synth_plan(torch, T, B, 500, 500, 9, 'cuda')
+wp = synth_plan(torch, T, B, params.map_size[0], params.map_size[1], 9, 'cuda')
 env.state.plan_ok.fill_(1); env.state.wp_valid.fill_(1)
 st = env.state.struct(); cfg = env.cfg; fn = env.backend.fn['run_stages']
 sp = C.c_void_p(torch.cuda.current_stream().cuda_stream)
