@@ -548,13 +548,23 @@ __device__ __forceinline__ int ray_cull(const d2d_cfg &c, int lane, const LdsVie
 }
 
 // Per-ray setup (utils.py:594,626-650): direction steps and the conservative candidate mask.
-struct Ray {
+// `M`: the mask type = how many candidates of an env the mask path takes (32, or 64 where an env can have more than 32
+// agents: at BASELINE config 3's 172 agents a fifth of the env-steps have 33..52 candidates, and without a mask every sample
+// of every ray would test all of them).
+template <typename M>
+struct RayT {
   double xs, ys;
-  unsigned int cmask;
+  M cmask;
 };
+template <typename M>
+__device__ __forceinline__ int mask_first(M m) {  // index of the lowest set bit
+  if constexpr (sizeof(M) == 8) return __ffsll((long long)m) - 1;
+  else return __ffs((int)m) - 1;
+}
 
-__device__ __forceinline__ Ray ray_setup(const d2d_cfg &c, const LdsView &L, int i, int ncand, double x0, double y0,
-                                         double yaw0) {
+template <typename M>
+__device__ __forceinline__ RayT<M> ray_setup(const d2d_cfg &c, const LdsView &L, int i, int ncand, double x0, double y0,
+                                             double yaw0) {
   const double ss = c.scale - 1.0;  // x_step_size, utils.py:621
   const double rad90 = 0x1.921fb54442d18p+0, rad270 = 0x1.2d97c7f3321d2p+2;  // radians(90), radians(270)
   const double pi_ = 0x1.921fb54442d18p+1;
@@ -567,7 +577,7 @@ __device__ __forceinline__ Ray ray_setup(const d2d_cfg &c, const LdsView &L, int
 #else
   double slope = d2d_tan(ang);
 #endif
-  Ray ry;
+  RayT<M> ry;
   if (fabs(slope) > 1.0) {
     slope = 1.0 / slope;
     ry.ys = faced_up ? -ss : ss;
@@ -580,14 +590,14 @@ __device__ __forceinline__ Ray ray_setup(const d2d_cfg &c, const LdsView &L, int
   // the drone.  Conservative (margins cover the rounding of the iterated sample positions); the exact
   // per-sample circle test of the reference is then applied to the set bits only.
   ry.cmask = 0;
-  if (ncand <= 32) {
+  if (ncand <= (int)(8 * sizeof(M))) {
     const double len2 = ry.xs * ry.xs + ry.ys * ry.ys, l1 = fabs(ry.xs) + fabs(ry.ys);
     for (int q = 0; q < ncand; ++q) {
       const double ex = L.cx[q] - x0, ey = L.cy[q] - y0, rq = L.crr[q] + 1e-6;
       const double cr = ex * ry.ys - ey * ry.xs, dt = ex * ry.xs + ey * ry.ys;
       const bool near_line = cr * cr <= rq * rq * len2 * (1.0 + 1e-9);
       const bool ahead = dt + rq * l1 >= 0.0;
-      ry.cmask |= (near_line && ahead) ? (1u << q) : 0u;
+      ry.cmask |= (near_line && ahead) ? (M)((M)1 << q) : (M)0;
     }
   }
   return ry;
@@ -601,14 +611,14 @@ __device__ __forceinline__ Ray ray_setup(const d2d_cfg &c, const LdsView &L, int
 // GENERAL: some ray of the wave has more than one candidate (or the env more than 32): the per-sample LDS
 // candidate loops are compiled in.  The common instantiation tests only the register-held first candidate.
 // FULL: L.gtw / L.dmt are copies of the WHOLE grids (Geom.full), indexed by the cell itself -- no window / crop arithmetic.
-template <bool GENERAL, bool FULL>
-__device__ __forceinline__ void ray_march(const d2d_cfg &c, const Geom &g, const LdsView &L, const Ray &ry, bool active,
+template <bool GENERAL, bool FULL, typename M>
+__device__ __forceinline__ void ray_march(const d2d_cfg &c, const Geom &g, const LdsView &L, const RayT<M> &ry, bool active,
                                           int ncand, double x0, double y0, const Tile &wt, const Tile &ct, bool patch,
                                           unsigned char *__restrict__ dm) {
   const int H = c.H;
   const CellDiv cell(c.scale, fmax(c.W_px, c.H_px));
   const double depth2 = c.depth * c.depth;
-  const bool mask_path = ncand <= 32;
+  const bool mask_path = ncand <= (int)(8 * sizeof(M));
   const unsigned char *gtw = (const unsigned char *)L.gtw;
   unsigned char *dmt = (unsigned char *)L.dmt;
   // sample 0 (the drone's own position, the same for every ray) was decided once by the caller
@@ -617,11 +627,11 @@ __device__ __forceinline__ void ray_march(const d2d_cfg &c, const Geom &g, const
   const int klo = g.klo;
   // The first candidate of this ray's mask (almost always the only one) is tested from registers on every
   // sample, branch-free; further candidates (rare) go through the LDS loop.
-  const bool has1 = mask_path && ry.cmask != 0u;
-  const int q1 = has1 ? (__ffs((int)ry.cmask) - 1) : 0;
+  const bool has1 = mask_path && ry.cmask != (M)0;
+  const int q1 = has1 ? mask_first(ry.cmask) : 0;
   const double c1x = L.cx[q1], c1y = L.cy[q1], c1r2 = has1 ? L.cr2[q1] : -1.0;
   const int c1i = L.cidx[q1];
-  const unsigned int rest = mask_path ? (ry.cmask & (ry.cmask - 1u)) : 0u;
+  const M rest = mask_path ? (M)(ry.cmask & (ry.cmask - (M)1)) : (M)0;
   auto sample = [&](auto far_tag) {
     constexpr bool FAR = decltype(far_tag)::value;
     // exact circle tests (utils.py:658-662): every candidate that can matter, no early-out among agents
@@ -632,10 +642,10 @@ __device__ __forceinline__ void ray_march(const d2d_cfg &c, const Geom &g, const
       if (any) L.hit[c1i] = 1;
     }
     if (GENERAL && mask_path) {
-      unsigned int m = alive ? rest : 0u;
+      M m = alive ? rest : (M)0;
       while (m) {
-        const int q = __ffs((int)m) - 1;
-        m &= m - 1;
+        const int q = mask_first(m);
+        m &= m - (M)1;
         const double dx = L.cx[q] - x, dy = L.cy[q] - y;
         if (dx * dx + dy * dy <= L.cr2[q]) {
           L.hit[L.cidx[q]] = 1;
@@ -1265,9 +1275,11 @@ __device__ __forceinline__ void store_regs(const d2d_state &s, int e, const EnvR
 //    per-ray tan / candidate work runs while they are in flight.
 // FULL (Geom.full, the specialised 50 x 50 geometry): both grids are staged WHOLE in LDS by DMA in batch 1 -- there is no
 // batch 2 at all: rays, collision probes, the dynamic-grid update and the observation crop read the copies.
-template <bool FULL>
+// WIDE: 64 ray candidates on the mask path (spec_wide).
+template <bool FULL, bool WIDE>
 __device__ __forceinline__ void run_env(const d2d_cfg &c, const d2d_state &s, int e, int lane, uint32_t stages,
                                         const Geom &g, const LdsView &L, double action, EnvRegs &r, size_t noise_off = 0) {
+  using RayMask = std::conditional_t<WIDE, unsigned long long, unsigned int>;
   const int N = c.N, W = c.W, H = c.H;
   const double inv_scale = 1.0 / c.scale;
   const bool do_ray = stages & D2D_ST_RAYCAST, do_dyn = stages & D2D_ST_DYNGRID, do_trk = stages & D2D_ST_TRACKER;
@@ -1363,7 +1375,7 @@ __device__ __forceinline__ void run_env(const d2d_cfg &c, const d2d_state &s, in
     bool go = false;  // do the rays continue past sample 0?
     for (int i0 = 0; i0 < c.R; i0 += WAVE) {
       const int i = i0 + lane;
-      const Ray ry = ray_setup(c, L, i, ncand, x0, y0, yaw0);
+      const RayT<RayMask> ry = ray_setup<RayMask>(c, L, i, ncand, x0, y0, yaw0);
       if (i0 == 0) {  // the tracker DMA and the tiles / grids have to be in LDS before the first sample reads / patches them
         landed();
         D2D_STAMP(5);
@@ -1397,7 +1409,7 @@ __device__ __forceinline__ void run_env(const d2d_cfg &c, const d2d_state &s, in
           go = (w0 != D2D_OCCUPIED);
         }
       }
-      const bool general = ncand > 32 || __any((ry.cmask & (ry.cmask - 1u)) != 0u);
+      const bool general = ncand > (int)(8 * sizeof(RayMask)) || __any((ry.cmask & (ry.cmask - (RayMask)1)) != (RayMask)0);
       if (general) ray_march<true, FULL>(c, g, L, ry, go && i < c.R, ncand, x0, y0, wt, ct, do_obs, dm);
       else ray_march<false, FULL>(c, g, L, ry, go && i < c.R, ncand, x0, y0, wt, ct, do_obs, dm);
     }
@@ -1474,6 +1486,11 @@ __host__ __device__ constexpr int spec_ncap(int spec) { return spec == 1 ? 16 : 
 // 5 KB more per wave cost occupancy in the persistent loop -- measured on BASELINE config 4 (24 agents): 4.9e7 env-steps/s
 // with whole grids against 5.5e7 with the window / crop tiles; config 3 (172 agents): 8 -> 6 waves per CU, the step 35 % slower.
 __host__ __device__ constexpr bool spec_full(int spec) { return spec == 1; }
+// 64 ray candidates on the mask path instead of 32: the default geometry with more than 32 agents (BASELINE config 3: 172 agents
+// on 500 x 500 px).  Not the generic kernel: it is at its scalar-register limit (the per-lane predicates of the march live in
+// SGPR pairs) and the wider mask costs config 5 -- 100 agents on 6400 x 6400 px, hardly ever a candidate -- a quarter of its
+// raycast time in spilled scalars.
+__host__ __device__ constexpr bool spec_wide(int spec) { return spec == 3; }
 __host__ __device__ inline bool spec_default_matches(const d2d_cfg &c) {
   return c.W == 50 && c.H == 50 && c.R == 50 && c.L == 33 && c.dt == 0.1 && c.scale == 10.0 &&
          c.W_px == 500.0 && c.H_px == 500.0 && c.ray_off0 == -0x1.921fb54442d18p-1 && c.ray_dth == 0x1.015bf9217271ap-5 &&
@@ -1517,7 +1534,7 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK, D2D_MIN_WAVES) void k_stages
     r.x = pin[(size_t)e * 2];
     r.y = pin[(size_t)e * 2 + 1];
   }
-  run_env<spec_full(SPEC)>(c, s, e, lane, stages, g, L, s.action[e], r);
+  run_env<spec_full(SPEC), spec_wide(SPEC)>(c, s, e, lane, stages, g, L, s.action[e], r);
   if (lane == 0) {
     store_regs(s, e, r);
     if (coll_out) coll_out[e] = s.flags[(size_t)e * 4 + D2D_F_COLLISION];
@@ -1679,7 +1696,7 @@ __device__ __attribute__((noinline)) void ph_gaze_stages(const ClosedArgs *ap, i
   load_regs(a->s, e, r);
   // this step's row of the measurement noise (d2d_cfg.noise_rows; utils.py:605 draws fresh normals every step)
   const size_t noise_off = c.noise_rows > 1 ? (size_t)(tstep % c.noise_rows) * c.B * c.N * 2 : 0;
-  run_env<spec_full(SPEC)>(c, a->s, e, lane, STAGES, g, L, a->s.action[e], r, noise_off);
+  run_env<spec_full(SPEC), spec_wide(SPEC)>(c, a->s, e, lane, STAGES, g, L, a->s.action[e], r, noise_off);
   if (lane == 0) store_regs(a->s, e, r);
   wave_sync_global();
 }
@@ -1696,7 +1713,7 @@ __device__ __attribute__((noinline)) void ph_stages(const ClosedArgs *ap, int e_
   const LdsView L = carve(base, g, c.L);
   EnvRegs r;
   load_regs(a->s, e, r);
-  run_env<spec_full(SPEC)>(c, a->s, e, lane, STAGES, g, L, a->s.action[e], r);
+  run_env<spec_full(SPEC), spec_wide(SPEC)>(c, a->s, e, lane, STAGES, g, L, a->s.action[e], r);
   if (lane == 0) store_regs(a->s, e, r);
   wave_sync_global();
 }
