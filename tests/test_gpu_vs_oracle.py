@@ -316,3 +316,46 @@ def test_measurement_noise_input(pkg, hip, oracle):
             env.step(a)
         _assert_same(dev, ref, f'step {t + 1}')
     assert int(dev.state.active.sum()) > 0
+
+
+def test_many_agent_raycast_candidates_at_the_cone_edges(pkg, hip, oracle):
+    """More than 32 agents on the default geometry: the raycast keeps only agents within their radius of the cone the rays
+    span (csrc ray_cull<CONE>, edges from float trigonometry under a margin) and tests up to 64 of them through a per-ray bit
+    mask.  72 standing agents per env on rings around the drone, bunched within +-12 degrees of the two edges of the field of
+    view, 48 start yaws, the view swinging over them for 12 steps: hit masks and every other field equal the oracle's
+    (which tests every agent at every sample, utils.py:658-662)."""
+    from drone2d_amd import _abi as A
+    B, N = 48, 72
+    dev, ref = _pair(pkg, hip, oracle, B, agent_number=N, agent_radius=8, agent_max_speed=5, map_id=21, init_pos=[250, 250],
+                     drone_max_speed=40)
+    assert dev.cfg.N > 32 and dev.cfg.W == 50 and dev.cfg.R == 50      # default geometry, more than 32 agents: the many-agent kernel
+    fov = np.radians(dev.params.drone_view_range)
+    ag = ref.state.agents.clone()
+    yaw = torch.zeros(B, dtype=torch.float64)
+    for e in range(B):
+        yaw[e] = (e * 7.5 + 0.25 * (e % 3)) % 360
+        pa = 2 * np.pi - np.radians(float(yaw[e]))
+        k = 0
+        for edge in (pa - fov / 2, pa + fov / 2):
+            for off in (-12, -6, -3, -1, 0, 1, 3, 6, 12):
+                for dist in (15.0, 40.0, 70.0, 90.0):
+                    a = edge + np.radians(off + 0.37 * (e % 5))
+                    ag[e, A.A_PX, k] = 250.0 + dist * np.cos(a)
+                    ag[e, A.A_PY, k] = 250.0 + dist * np.sin(a)
+                    k += 1
+        assert k == N
+    ag[:, A.A_VX] = 0.0
+    ag[:, A.A_VY] = 0.0
+    for env in (dev, ref):
+        env.state.agents.copy_(ag)
+        env.state.drone[:, A.D_YAW] = yaw.to(env.state.drone.device)
+    rng = np.random.RandomState(8)
+    hits = 0
+    for t in range(12):
+        a = rng.choice([-1.0, -0.4, 0.3, 1.0], B)
+        dev.step(a)
+        ref.step(a)
+        _assert_same(dev, ref, f'cone edges step {t + 1}')
+        hits += int(ref.state.hit.sum())
+    per_env = ref.state.hit.sum(1)
+    assert hits > 12 * B * 4 and int(per_env.min()) > 0 and int(per_env.max()) < N
