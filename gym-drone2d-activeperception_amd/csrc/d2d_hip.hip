@@ -128,12 +128,12 @@ struct FastDiv {
 
 struct LdsView {
   double *ax, *ay, *ar, *ar2;    // all agents of the env after this step's move   [ncap]
-  double *cx, *cy, *cr2, *crr;   // compacted ray candidates (centre, r^2, r)      [ncap]
+  double *cx, *cy, *cr2, *crr;   // compacted ray candidates (centre, r^2, r)      [ccap]
   double *kf;                    // tracker state staged in batch 1 by DMA         [ncap][20] (if g.kf_lds)
-  int *cidx;                     // candidate -> agent index                        [ncap]
-  int *ncx, *ncy, *nu;           // new dynamic block of every agent (cell, half)   [ncap]
-  int *pcx, *pcy, *pu;           // block written last time (dyn_prev)              [ncap]
+  int *cidx;                     // candidate -> agent index                        [ccap]
   int *klen;                     // len(tracker.ts)                                 [ncap]
+  short *ncx, *ncy, *nu;         // new dynamic block of every agent (cell, half)   [ncap]  (grids are at most 32767 cells
+  short *pcx, *pcy, *pu;         // block written last time (dyn_prev)              [ncap]   wide: check())
   unsigned int *bm;              // bitmap of cells covered by some agent's new block [bmw]
   unsigned int *gtw;             // ground-truth window tile, bytes                 [ws][ws]
   unsigned int *dmt;             // drone-map crop tile, bytes                      [L][L]
@@ -142,6 +142,8 @@ struct LdsView {
 
 struct Geom {
   int ncap;   // N rounded up to a multiple of 4
+  int ccap;   // ray candidates kept in LDS: min(ncap, 64).  An env with more candidates than that (a crowd inside the cone of
+              // the rays) tests every agent at every sample instead, as the reference does.
   int reach;  // cells a ray can travel from the drone cell
   int ws;     // window edge = 2 * reach + 1
   int wdw;    // dwords of the window tile
@@ -162,6 +164,7 @@ __host__ __device__ inline Geom make_geom(const d2d_cfg &c, int wpb, int ncap_fi
   g.ncap = (c.N + 3) & ~3;
   if (g.ncap < 4) g.ncap = 4;
   if (ncap_fixed) g.ncap = ncap_fixed;
+  g.ccap = g.ncap < 64 ? g.ncap : 64;
   g.reach = (int)((c.depth + 1.5 * (c.scale - 1.0)) / c.scale) + 2;
   g.ws = 2 * g.reach + 1;
   g.wdw = (g.ws * g.ws + 3) / 4;   // dwords of the window tile
@@ -184,7 +187,8 @@ __host__ __device__ inline Geom make_geom(const d2d_cfg &c, int wpb, int ncap_fi
     g.bmw = 0;
     g.bmhash = 0;
   }
-  const int base = 64 * g.ncap + 32 * g.ncap + 4 * g.bmw + 4 * g.wdw + 4 * g.ldw + 2 * g.ncap;
+  // per agent: 4 doubles, klen, 6 shorts, hit + act; per candidate: 4 doubles + index
+  const int base = (32 + 4 + 12 + 2) * g.ncap + 36 * g.ccap + 4 * g.bmw + 4 * g.wdw + 4 * g.ldw;
   g.kf_lds = (c.kf_enabled && ((base + 160 * g.ncap + 15) & ~15) * wpb <= 64 * 1024) ? 1 : 0;
   g.wave_bytes = (base + (g.kf_lds ? 160 * g.ncap : 0) + 15) & ~15;
   return g;
@@ -197,22 +201,22 @@ __device__ __forceinline__ LdsView carve(char *base, const Geom &g, int Lm) {
   L.ar = L.ay + g.ncap;
   L.ar2 = L.ar + g.ncap;
   L.cx = L.ar2 + g.ncap;
-  L.cy = L.cx + g.ncap;
-  L.cr2 = L.cy + g.ncap;
-  L.crr = L.cr2 + g.ncap;
-  L.kf = L.crr + g.ncap;
+  L.cy = L.cx + g.ccap;
+  L.cr2 = L.cy + g.ccap;
+  L.crr = L.cr2 + g.ccap;
+  L.kf = L.crr + g.ccap;
   L.cidx = (int *)(L.kf + (g.kf_lds ? 20 * g.ncap : 0));
-  L.ncx = L.cidx + g.ncap;
+  L.klen = L.cidx + g.ccap;
+  L.bm = (unsigned int *)(L.klen + g.ncap);
+  L.gtw = L.bm + g.bmw;
+  L.dmt = L.gtw + g.wdw;
+  L.ncx = (short *)(L.dmt + g.ldw);  // ncap is a multiple of 4: every plane below stays 8-byte aligned
   L.ncy = L.ncx + g.ncap;
   L.nu = L.ncy + g.ncap;
   L.pcx = L.nu + g.ncap;
   L.pcy = L.pcx + g.ncap;
   L.pu = L.pcy + g.ncap;
-  L.klen = L.pu + g.ncap;
-  L.bm = (unsigned int *)(L.klen + g.ncap);
-  L.gtw = L.bm + g.bmw;
-  L.dmt = L.gtw + g.wdw;
-  L.hit = (unsigned char *)(L.dmt + g.ldw);
+  L.hit = (unsigned char *)(L.pu + g.ncap);
   L.act = L.hit + g.ncap;
   return L;
 }
@@ -520,7 +524,8 @@ __device__ __forceinline__ double positive_angle(double a) {
 // fast float sine / cosine (|error| < 1e-5 of a direction = 1e-3 px at the end of a ray) under a margin of 0.05 px; the
 // exact per-sample tests decide among the survivors as before.  A view of 90 degrees keeps about a third of the disc's agents.
 template <bool CONE>
-__device__ __forceinline__ int ray_cull(const d2d_cfg &c, int lane, const LdsView &L, double x0, double y0, double yaw0) {
+__device__ __forceinline__ int ray_cull(const d2d_cfg &c, int lane, const LdsView &L, double x0, double y0, double yaw0,
+                                        int ccap) {
   const int N = c.N;
   const double ss = c.scale - 1.0;
   int ncand = 0;
@@ -557,8 +562,8 @@ __device__ __forceinline__ int ray_cull(const d2d_cfg &c, int lane, const LdsVie
       L.hit[k] = 0;
     }
     const unsigned long long m = __ballot(cand);
-    if (cand) {
-      const int slot = ncand + __popcll(m & ((1ull << lane) - 1ull));
+    const int slot = ncand + __popcll(m & ((1ull << lane) - 1ull));
+    if (cand && slot < ccap) {  // beyond the capacity the count alone matters: such an env tests every agent (Geom.ccap)
       L.cx[slot] = px;
       L.cy[slot] = py;
       L.cr2[slot] = r2;
@@ -676,11 +681,21 @@ __device__ __forceinline__ void ray_march(const d2d_cfg &c, const Geom &g, const
         }
       }
     } else if (GENERAL && alive) {
-      for (int q = 0; q < ncand; ++q) {
-        const double dx = L.cx[q] - x, dy = L.cy[q] - y;
-        if (dx * dx + dy * dy <= L.cr2[q]) {
-          L.hit[L.cidx[q]] = 1;
-          any = true;
+      if (ncand <= g.ccap) {
+        for (int q = 0; q < ncand; ++q) {
+          const double dx = L.cx[q] - x, dy = L.cy[q] - y;
+          if (dx * dx + dy * dy <= L.cr2[q]) {
+            L.hit[L.cidx[q]] = 1;
+            any = true;
+          }
+        }
+      } else {  // a crowd: more candidates than the LDS list holds -- every agent, as utils.py:658-662 does
+        for (int k = 0; k < c.N; ++k) {
+          const double dx = L.ax[k] - x, dy = L.ay[k] - y;
+          if (dx * dx + dy * dy <= L.ar2[k]) {
+            L.hit[k] = 1;
+            any = true;
+          }
         }
       }
     }
@@ -1298,8 +1313,8 @@ __device__ __forceinline__ void store_regs(const d2d_state &s, int e, const EnvR
 //    per-ray tan / candidate work runs while they are in flight.
 // FULL (Geom.full, the specialised 50 x 50 geometry): both grids are staged WHOLE in LDS by DMA in batch 1 -- there is no
 // batch 2 at all: rays, collision probes, the dynamic-grid update and the observation crop read the copies.
-// WIDE: 64 ray candidates on the mask path (spec_wide).
-template <bool FULL, bool WIDE>
+// WIDE: 64 ray candidates on the mask path (spec_wide).  CONE: candidates culled against the cone of the rays (spec_cone).
+template <bool FULL, bool WIDE, bool CONE>
 __device__ __forceinline__ void run_env(const d2d_cfg &c, const d2d_state &s, int e, int lane, uint32_t stages,
                                         const Geom &g, const LdsView &L, double action, EnvRegs &r, size_t noise_off = 0) {
   using RayMask = std::conditional_t<WIDE, unsigned long long, unsigned int>;
@@ -1370,7 +1385,7 @@ __device__ __forceinline__ void run_env(const d2d_cfg &c, const d2d_state &s, in
   // ---------------- raycast: setup while the loads are in flight ----------------
   int ncand = 0;
   if (do_ray) {
-    ncand = ray_cull<WIDE>(c, lane, L, x0, y0, yaw0);
+    ncand = ray_cull<CONE>(c, lane, L, x0, y0, yaw0, g.ccap);
 #ifdef D2D_ABL_NOCAND
     ncand = 0;
 #endif
@@ -1406,11 +1421,21 @@ __device__ __forceinline__ void run_env(const d2d_cfg &c, const d2d_state &s, in
         // agent covering it stops every ray before the map is touched (:658-664), else its cell is recorded.
         go = (0.0 < x0 && x0 < c.W_px && 0.0 < y0 && y0 < c.H_px);
         bool cover = false;
-        for (int q = lane; q < ncand; q += WAVE) {
-          const double dx = L.cx[q] - x0, dy = L.cy[q] - y0;
-          if (go && dx * dx + dy * dy <= L.cr2[q]) {
-            L.hit[L.cidx[q]] = 1;
-            cover = true;
+        if (ncand <= g.ccap) {
+          for (int q = lane; q < ncand; q += WAVE) {
+            const double dx = L.cx[q] - x0, dy = L.cy[q] - y0;
+            if (go && dx * dx + dy * dy <= L.cr2[q]) {
+              L.hit[L.cidx[q]] = 1;
+              cover = true;
+            }
+          }
+        } else {  // a crowd (Geom.ccap): the list is incomplete, every agent is asked
+          for (int k = lane; k < N; k += WAVE) {
+            const double dx = L.ax[k] - x0, dy = L.ay[k] - y0;
+            if (go && dx * dx + dy * dy <= L.ar2[k]) {
+              L.hit[k] = 1;
+              cover = true;
+            }
           }
         }
         go = go && !__any(cover);
@@ -1514,6 +1539,8 @@ __host__ __device__ constexpr bool spec_full(int spec) { return spec == 1; }
 // SGPR pairs) and the wider mask costs config 5 -- 100 agents on 6400 x 6400 px, hardly ever a candidate -- a quarter of its
 // raycast time in spilled scalars.
 __host__ __device__ constexpr bool spec_wide(int spec) { return spec == 3; }
+// ray candidates culled against the cone of the rays (ray_cull<true>): where an env has enough agents for it to pay
+__host__ __device__ constexpr bool spec_cone(int spec) { return spec == 2 || spec == 3; }
 __host__ __device__ inline bool spec_default_matches(const d2d_cfg &c) {
   return c.W == 50 && c.H == 50 && c.R == 50 && c.L == 33 && c.dt == 0.1 && c.scale == 10.0 &&
          c.W_px == 500.0 && c.H_px == 500.0 && c.ray_off0 == -0x1.921fb54442d18p-1 && c.ray_dth == 0x1.015bf9217271ap-5 &&
@@ -1557,7 +1584,7 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK, D2D_MIN_WAVES) void k_stages
     r.x = pin[(size_t)e * 2];
     r.y = pin[(size_t)e * 2 + 1];
   }
-  run_env<spec_full(SPEC), spec_wide(SPEC)>(c, s, e, lane, stages, g, L, s.action[e], r);
+  run_env<spec_full(SPEC), spec_wide(SPEC), spec_cone(SPEC)>(c, s, e, lane, stages, g, L, s.action[e], r);
   if (lane == 0) {
     store_regs(s, e, r);
     if (coll_out) coll_out[e] = s.flags[(size_t)e * 4 + D2D_F_COLLISION];
@@ -1719,7 +1746,7 @@ __device__ __attribute__((noinline)) void ph_gaze_stages(const ClosedArgs *ap, i
   load_regs(a->s, e, r);
   // this step's row of the measurement noise (d2d_cfg.noise_rows; utils.py:605 draws fresh normals every step)
   const size_t noise_off = c.noise_rows > 1 ? (size_t)(tstep % c.noise_rows) * c.B * c.N * 2 : 0;
-  run_env<spec_full(SPEC), spec_wide(SPEC)>(c, a->s, e, lane, STAGES, g, L, a->s.action[e], r, noise_off);
+  run_env<spec_full(SPEC), spec_wide(SPEC), spec_cone(SPEC)>(c, a->s, e, lane, STAGES, g, L, a->s.action[e], r, noise_off);
   if (lane == 0) store_regs(a->s, e, r);
   wave_sync_global();
 }
@@ -1736,7 +1763,7 @@ __device__ __attribute__((noinline)) void ph_stages(const ClosedArgs *ap, int e_
   const LdsView L = carve(base, g, c.L);
   EnvRegs r;
   load_regs(a->s, e, r);
-  run_env<spec_full(SPEC), spec_wide(SPEC)>(c, a->s, e, lane, STAGES, g, L, a->s.action[e], r);
+  run_env<spec_full(SPEC), spec_wide(SPEC), spec_cone(SPEC)>(c, a->s, e, lane, STAGES, g, L, a->s.action[e], r);
   if (lane == 0) store_regs(a->s, e, r);
   wave_sync_global();
 }
@@ -1837,6 +1864,7 @@ int check(const d2d_cfg *c, const d2d_state *s) {
   if (c->abi_version != D2D_ABI_VERSION) return fail(-2, "ABI version mismatch");
   if (c->B < 0 || c->N < 0 || c->W <= 0 || c->H <= 0 || c->R <= 0 || c->L <= 0 || (c->L & 1) == 0 || c->T <= 0)
     return fail(-1, "bad dimensions");
+  if (c->W > 32767 || c->H > 32767) return fail(-4, "grids of more than 32767 cells a side are not supported (16-bit cell planes in LDS)");
   if (!(c->scale >= 2.0) || c->scale != (double)(long long)c->scale)
     return fail(-4, "map_scale must be an integer >= 2 (scale 1 never advances a ray, utils.py:621)");
   if (!(c->depth > 0) || !(c->dt > 0)) return fail(-1, "bad depth / dt");

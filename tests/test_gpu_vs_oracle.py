@@ -256,11 +256,11 @@ def test_per_step_measurement_noise_rows(pkg, hip, oracle):
 
 
 def test_single_wave_above_64k_of_lds(pkg, hip, oracle):
-    """720 agents: the per-env LDS working set (73 KB) is above the 64 KB a workgroup gets by default -- round 1 refused such a
+    """1400 agents: the per-env LDS working set (73 KB) is above the 64 KB a workgroup gets by default -- round 1 refused such a
     configuration (-4); now the wave gets a workgroup of its own with the kernel opted into more dynamic LDS
     (hipFuncAttributeMaxDynamicSharedMemorySize).  Device vs oracle, every field."""
     from drone2d_amd import _lib
-    dev, ref = _pair(pkg, hip, oracle, 3, agent_number=720, agent_radius=4, agent_max_speed=20, map_id=2, map_size=[1000, 1000],
+    dev, ref = _pair(pkg, hip, oracle, 3, agent_number=1400, agent_radius=4, agent_max_speed=20, map_id=2, map_size=[1000, 1000],
                      init_pos=[500, 500], target_list=[[900, 900]])
     wpb, lds, per_cu, spec = _lib.launch_shape(dev.cfg)
     assert wpb == 1 and lds > 64 * 1024 and per_cu >= 2 and spec == 0
@@ -269,7 +269,7 @@ def test_single_wave_above_64k_of_lds(pkg, hip, oracle):
         a = rng.uniform(-1, 1, 3)
         dev.step(a)
         ref.step(a)
-        _assert_same(dev, ref, f'720 agents step {t + 1}')
+        _assert_same(dev, ref, f'1400 agents step {t + 1}')
     assert int(ref.state.hit.sum()) > 0
 
 
@@ -359,3 +359,22 @@ def test_many_agent_raycast_candidates_at_the_cone_edges(pkg, hip, oracle):
         hits += int(ref.state.hit.sum())
     per_env = ref.state.hit.sum(1)
     assert hits > 12 * B * 4 and int(per_env.min()) > 0 and int(per_env.max()) < N
+    # a crowd: all 72 agents inside the cone, more candidates than the 64 the LDS list holds -- such an env tests every agent at
+    # every sample (Geom.ccap); the nearest ring shadows the others, hit masks equal the oracle's again
+    ag2 = ref.state.agents.clone()
+    yaw2 = ref.state.drone[:, A.D_YAW].clone()
+    for e in range(B):
+        pa = 2 * np.pi - np.radians(float(yaw2[e]))
+        for k in range(N):
+            a = pa + (k % 12 - 5.5) / 12.0 * fov * 0.9
+            d = 22.0 + 11.0 * (k // 12) + 0.3 * (e % 7)
+            ag2[e, A.A_PX, k] = 250.0 + d * np.cos(a)
+            ag2[e, A.A_PY, k] = 250.0 + d * np.sin(a)
+    for env in (dev, ref):
+        env.state.agents.copy_(ag2)
+    for t in range(4):
+        a = rng.choice([-0.5, 0.0, 0.5], B)
+        dev.step(a)
+        ref.step(a)
+        _assert_same(dev, ref, f'crowd step {t + 1}')
+    assert int(ref.state.hit.sum(1).min()) >= 6
