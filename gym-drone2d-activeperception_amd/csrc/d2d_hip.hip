@@ -189,7 +189,10 @@ __host__ __device__ inline Geom make_geom(const d2d_cfg &c, int wpb, int ncap_fi
   }
   // per agent: 4 doubles, klen, 6 shorts, hit + act; per candidate: 4 doubles + index
   const int base = (32 + 4 + 12 + 2) * g.ncap + 36 * g.ccap + 4 * g.bmw + 4 * g.wdw + 4 * g.ldw;
-  g.kf_lds = (c.kf_enabled && ((base + 160 * g.ncap + 15) & ~15) * wpb <= 64 * 1024) ? 1 : 0;
+  // tracker state staged in LDS only while the wave stays within the 10 KB that keep 16 waves on a CU: beyond that the
+  // occupancy it would cost is worth more than the staging (the trackers then come straight from global memory)
+  g.kf_lds = (c.kf_enabled && ((base + 160 * g.ncap + 15) & ~15) <= 10240) ? 1 : 0;
+  (void)wpb;
   g.wave_bytes = (base + (g.kf_lds ? 160 * g.ncap : 0) + 15) & ~15;
   return g;
 }
@@ -1557,11 +1560,34 @@ __device__ __forceinline__ void spec_default_apply(d2d_cfg &c) {
 
 extern __shared__ __attribute__((aligned(16))) char d2d_lds[];
 
+// The kernel's own argument block as it lies in the kernarg segment (constant memory).  The generic kernel reads the
+// configuration and the state's pointers THROUGH it, field by field where they are used, instead of from the by-value
+// parameters: those are all fetched on entry and stay live to the end -- some 130 scalar registers of arguments against the
+// 102 there are, i.e. hundreds of spill reloads (v_readlane) inside the ray and agent loops.  The specialised kernels fold
+// the configuration into constants and do not need this.
+struct StagesKArgs {
+  d2d_cfg c;
+  d2d_state s;
+  uint32_t stages;
+  const double *pin;
+  unsigned char *coll_out;
+};
+
 template <int SPEC>
-__global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK, D2D_MIN_WAVES) void k_stages(d2d_cfg c_in, d2d_state s, uint32_t stages,
+__global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK, D2D_MIN_WAVES) void k_stages(d2d_cfg c_in, d2d_state s_in, uint32_t stages,
                                                                                  const double *pin, unsigned char *coll_out) {
-  d2d_cfg c = c_in;
-  if (SPEC != 0) spec_default_apply(c);
+#if defined(__HIP_DEVICE_COMPILE__)
+  const StagesKArgs *ka = (const StagesKArgs *)(const __attribute__((address_space(4))) StagesKArgs *)__builtin_amdgcn_kernarg_segment_ptr();
+#else
+  const StagesKArgs *ka = nullptr;  // the host pass only parses this
+#endif
+  d2d_cfg c_folded;
+  if (SPEC != 0) {
+    c_folded = c_in;
+    spec_default_apply(c_folded);
+  }
+  const d2d_cfg &c = SPEC != 0 ? c_folded : ka->c;
+  const d2d_state &s = SPEC != 0 ? s_in : ka->s;
   // wave-uniform by construction; readfirstlane tells the compiler, so every per-env base pointer and LDS
   // base lives in SGPRs and loads take the scalar-base + 32-bit-offset form
   const int lane = threadIdx.x & (WAVE - 1), wpb = (SPEC == 1 || SPEC == 2) ? WAVES_PER_BLOCK : (int)(blockDim.x / WAVE);
@@ -1851,12 +1877,29 @@ bool spec_path(const d2d_cfg &c) {
 #endif
 }
 
-// envs per workgroup: as many waves as fit the 64 KB budget (4, 2 or 1), one wave with up to 160 KB; 0 = does not fit at all
+// Envs (waves) per workgroup -- 4, 2 or 1 -- for a per-wave working set of bytes(wpb): the choice that puts the most waves on a
+// CU (workgroups of wpb * bytes within 64 KB, or a single wave with up to 160 KB, as many of them as 160 KB hold; 16 waves is
+// the register limit anyway).  Ties go to the larger workgroup.  0 = does not fit at all.  E.g. 16.9 KB per wave: 2 per
+// workgroup gives 4 workgroups = 8 waves, 1 per workgroup 9.
+template <typename F>
+int best_wpb(F bytes) {
+  int best = 0, best_waves = 0;
+  for (int wpb = WAVES_PER_BLOCK; wpb >= 1; wpb >>= 1) {
+    const size_t wg = (size_t)bytes(wpb) * wpb;
+    if (wg == 0 || wg > (wpb == 1 ? LDS_HARD : LDS_SOFT)) continue;
+    int waves = (int)(LDS_HARD / ((wg + 1023) & ~(size_t)1023)) * wpb;  // allocation granularity: be conservative
+    if (waves > 16) waves = 16;
+    if (waves > best_waves) {
+      best = wpb;
+      best_waves = waves;
+    }
+  }
+  return best;
+}
+
 int pick_wpb(const d2d_cfg &c) {
   const bool full = spec_path(c) && spec_full(c.N <= spec_ncap(1) ? 1 : (c.N <= spec_ncap(2) ? 2 : 3));
-  for (int wpb = WAVES_PER_BLOCK; wpb >= 1; wpb >>= 1)
-    if ((size_t)make_geom(c, wpb, 0, full).wave_bytes * wpb <= LDS_SOFT) return wpb;
-  return (size_t)make_geom(c, 1, 0, full).wave_bytes <= LDS_HARD ? 1 : 0;
+  return best_wpb([&](int wpb) { return make_geom(c, wpb, 0, full).wave_bytes; });
 }
 
 int check(const d2d_cfg *c, const d2d_state *s) {
@@ -2092,8 +2135,8 @@ int d2d_closed_loop(const d2d_cfg *c, const d2d_state *s, const d2d_plan *p, int
       return spec == 0 ? closed_wave_bytes<0>(*c, *p, wpb) : spec == 1 ? closed_wave_bytes<1>(*c, *p, wpb)
            : spec == 2 ? closed_wave_bytes<2>(*c, *p, wpb) : closed_wave_bytes<3>(*c, *p, wpb);
     };
-    int wpb = (spec == 1 || spec == 2) ? WAVES_PER_BLOCK : pick_wpb(*c);
-    while (wpb >= 1 && (size_t)bytes(wpb) * wpb > (wpb == 1 ? LDS_HARD : LDS_SOFT)) wpb = (spec == 1 || spec == 2) ? 0 : wpb / 2;
+    const int wpb = (spec == 1 || spec == 2) ? ((size_t)bytes(WAVES_PER_BLOCK) * WAVES_PER_BLOCK <= LDS_SOFT ? WAVES_PER_BLOCK : 0)
+                                             : best_wpb(bytes);
     if (wpb >= 1) {
       const dim3 grid((c->B + wpb - 1) / wpb), block(WAVE * wpb);
       const size_t lds = (size_t)bytes(wpb) * wpb;
@@ -2146,7 +2189,7 @@ int d2d_launch_shape(const d2d_cfg *c, const d2d_plan *p, int32_t out[4]) {
       return spec == 0 ? closed_wave_bytes<0>(*c, *p, w) : spec == 1 ? closed_wave_bytes<1>(*c, *p, w)
            : spec == 2 ? closed_wave_bytes<2>(*c, *p, w) : closed_wave_bytes<3>(*c, *p, w);
     };
-    while (wpb >= 1 && (size_t)bytes(wpb) * wpb > (wpb == 1 ? LDS_HARD : LDS_SOFT)) wpb = (spec == 1 || spec == 2) ? 0 : wpb / 2;
+    wpb = (spec == 1 || spec == 2) ? ((size_t)bytes(WAVES_PER_BLOCK) * WAVES_PER_BLOCK <= LDS_SOFT ? WAVES_PER_BLOCK : 0) : best_wpb(bytes);
     wb = wpb >= 1 ? (size_t)bytes(wpb) : 0;
     if (!p->launch_args || c->planner_mode != D2D_PLANNER_EXTERNAL) wpb = 0;
   }
