@@ -1541,9 +1541,9 @@ __host__ __device__ constexpr bool spec_full(int spec) { return spec == 1; }
 // on 500 x 500 px).  Not the generic kernel: it is at its scalar-register limit (the per-lane predicates of the march live in
 // SGPR pairs) and the wider mask costs config 5 -- 100 agents on 6400 x 6400 px, hardly ever a candidate -- a quarter of its
 // raycast time in spilled scalars.
-__host__ __device__ constexpr bool spec_wide(int spec) { return spec == 3; }
+__host__ __device__ constexpr bool spec_wide(int spec) { return spec == 3 || spec == 0; }
 // ray candidates culled against the cone of the rays (ray_cull<true>): where an env has enough agents for it to pay
-__host__ __device__ constexpr bool spec_cone(int spec) { return spec == 2 || spec == 3; }
+__host__ __device__ constexpr bool spec_cone(int spec) { return spec != 1; }
 __host__ __device__ inline bool spec_default_matches(const d2d_cfg &c) {
   return c.W == 50 && c.H == 50 && c.R == 50 && c.L == 33 && c.dt == 0.1 && c.scale == 10.0 &&
          c.W_px == 500.0 && c.H_px == 500.0 && c.ray_off0 == -0x1.921fb54442d18p-1 && c.ray_dth == 0x1.015bf9217271ap-5 &&
@@ -1587,7 +1587,7 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK, D2D_MIN_WAVES) void k_stages
     spec_default_apply(c_folded);
   }
   const d2d_cfg &c = SPEC != 0 ? c_folded : ka->c;
-  const d2d_state &s = SPEC != 0 ? s_in : ka->s;
+  const d2d_state &s = (SPEC == 1 || SPEC == 2) ? s_in : ka->s;  // the many-agent kernel folds cfg, but its state pointers spill too
   // wave-uniform by construction; readfirstlane tells the compiler, so every per-env base pointer and LDS
   // base lives in SGPRs and loads take the scalar-base + 32-bit-offset form
   const int lane = threadIdx.x & (WAVE - 1), wpb = (SPEC == 1 || SPEC == 2) ? WAVES_PER_BLOCK : (int)(blockDim.x / WAVE);

@@ -17,7 +17,12 @@ wl = os.environ.get('WORKLOAD')          # e.g. WORKLOAD=config5 B=8192: the sta
 if wl:
     params = pkg.Params(planner='Primitive', drone_max_speed=40, map_id=1, **WORKLOADS[wl][1])
 else:
-    params = pkg.Params(planner='Primitive', agent_number=int(os.environ.get('N', 10)), agent_radius=15, agent_max_speed=20, map_id=1)
+    extra = {}
+    if os.environ.get('MAP'):            # e.g. MAP=600,600: a non-default geometry (the generic kernel)
+        w, h = (int(v) for v in os.environ['MAP'].split(','))
+        extra = dict(map_size=[w, h], init_pos=[w // 2, h // 2], target_list=[[w - 60, h - 60]])
+    params = pkg.Params(planner='Primitive', agent_number=int(os.environ.get('N', 10)), agent_radius=int(os.environ.get('R', 15)),
+                        agent_max_speed=20, map_id=1, **extra)
 worlds = vec_env.build_worlds(params, min(B, int(os.environ.get('WORLDS', 512))), workers=int(os.environ.get('WORKERS', 0)))
 env = vec_env.VecDrone2DEnv(params, B, planner='external', worlds=[worlds[i % len(worlds)] for i in range(B)])
 T = 260
