@@ -150,8 +150,9 @@ struct Geom {
   int ldw;    // dwords of the crop tile
   int smax;   // samples after which every ray has stopped: sample k is >= k * ss from the drone
   int klo;    // samples 0..klo are < depth from the drone whatever the slope (k * ss * sqrt(2) < depth)
-  int bmw;    // dwords of the per-env cell bitmap kept in LDS, or (bmhash) slots of the hash set of covered cells
-  int bmhash; // grid too large for a bitmap (above 256 x 256 cells): the covered cells are kept as a hash set of cell indices
+  int bmw;    // dwords of the per-env cell bitmap kept in LDS (0: none)
+  int dyn2p;  // grid too large for a bitmap (above 256 x 256 cells): the dynamic-grid update runs in two phases instead (dyn_clear,
+              // dyn_mark) and needs no coverage structure at all
   int kf_lds; // tracker state staged in LDS (fits the 64 KB workgroup budget)
   int full;   // both grids staged WHOLE in LDS (the specialised 50 x 50 geometry): gtw / dmt are the full copies, no tiles, no bitmap
   int wave_bytes;
@@ -175,17 +176,16 @@ __host__ __device__ inline Geom make_geom(const d2d_cfg &c, int wpb, int ncap_fi
   g.klo = (int)kl - ((kl == (double)(int)kl) ? 1 : 0);
   if (g.klo < -1) g.klo = -1;
   g.bmw = (c.W * c.H + 31) / 32;
-  g.bmhash = 0;
-  if (g.bmw > 2048) {  // a bitmap above 8 KB per wave (256 x 256 cells): a hash set instead, >= 16 slots per agent (3 x 3 blocks: load < 0.6)
-    g.bmhash = 1;
-    g.bmw = 64;
-    while (g.bmw < 16 * g.ncap) g.bmw <<= 1;
+  g.dyn2p = 0;
+  if (g.bmw > 2048) {  // a bitmap above 8 KB per wave (256 x 256 cells): the two-phase update, no LDS
+    g.dyn2p = 1;
+    g.bmw = 0;
   }
   if (full) {  // whole grids: W * H bytes each (rounded to 16), the dynamic-grid coverage marks live in the gt copy itself
     g.wdw = ((c.W * c.H + 15) & ~15) / 4;
     g.ldw = g.wdw;
     g.bmw = 0;
-    g.bmhash = 0;
+    g.dyn2p = 0;
   }
   // per agent: 4 doubles, klen, 6 shorts, hit + act; per candidate: 4 doubles + index
   const int base = (32 + 4 + 12 + 2) * g.ncap + 36 * g.ccap + 4 * g.bmw + 4 * g.wdw + 4 * g.ldw;
@@ -748,25 +748,6 @@ __device__ __forceinline__ void ray_march(const d2d_cfg &c, const Geom &g, const
 #endif
 }
 
-// Is cell (i, j) inside the new block of ANY agent?  Straight loop, no early exit: the LDS reads are
-// broadcasts and pipeline.  Only used when the grid is too large for the LDS bitmap.
-__device__ __forceinline__ bool dyn_covered_loop(const LdsView &L, int N, int i, int j) {
-  bool cov = false;
-  for (int a = 0; a < N; ++a) cov = cov || (abs(i - L.ncx[a]) <= L.nu[a] && abs(j - L.ncy[a]) <= L.nu[a]);
-  return cov;
-}
-
-// ... by the new block of an agent whose block is wider than 3 x 3 cells (the hash set of dyn_bitmap holds the others).  The
-// wave-uniform test first: no such agent in the env (the usual case) -> nothing to walk.
-__device__ __forceinline__ bool dyn_covered_wide(const LdsView &L, int N, int i, int j) {
-  bool cov = false;
-  for (int a = 0; a < N; ++a) {
-    const int u = L.nu[a];
-    cov = cov || (u > 1 && abs(i - L.ncx[a]) <= u && abs(j - L.ncy[a]) <= u);
-  }
-  return cov;
-}
-
 // utils.py:527-540, lane = agent.  The reference clears every cell of dynamic_idx (== every DYNAMIC cell,
 // all of which lie in the blocks of dyn_prev) and then marks every agent's new block.  Written here as
 // ONE order-independent pass: the final value of a cell depends only on (static or not, covered by some
@@ -778,34 +759,12 @@ struct DynCells {  // the common case (blocks of at most 3 x 3 cells), reduced t
   unsigned int nfree;  // bit q: new-block cell q is neither static nor already DYNAMIC
 };
 
-// Returns (hash-set mode): does some agent of the env have a block wider than 3 x 3 cells (not in the set)?
-__device__ __forceinline__ bool dyn_bitmap(const d2d_cfg &c, int lane, const Geom &g, const LdsView &L) {
+// The LDS bitmap of the cells covered by some agent's new block (grids up to 256 x 256 cells; Geom.bmw == 0: none).
+__device__ __forceinline__ void dyn_bitmap(const d2d_cfg &c, int lane, const Geom &g, const LdsView &L) {
   const int N = c.N, W = c.W, H = c.H;
-  if (g.bmw == 0) return false;
+  if (g.bmw == 0) return;
   for (int w = lane; w < g.bmw; w += WAVE) L.bm[w] = 0u;
   wave_sync_lds();
-  if (g.bmhash) {  // hash set of the covered cells' indices (+ 1: 0 = empty slot), open addressing; blocks wider than 3 x 3 stay out
-    const unsigned int mask = (unsigned int)g.bmw - 1u;
-    bool wide = false;
-    for (int k = lane; k < N; k += WAVE) wide = wide || L.nu[k] > 1;
-    const bool any_wide = __any(wide);
-    for (int k = lane; k < N; k += WAVE) {
-      const int cx = L.ncx[k], cy = L.ncy[k], u = L.nu[k];
-      if (u > 1) continue;  // such an agent's cells are found by the loop over agents (dyn_covered_wide)
-      const int i1 = min(cx + u + 1, W), j1 = min(cy + u + 1, H);
-      for (int i = max(cx - u, 0); i < i1; ++i)
-        for (int j = max(cy - u, 0); j < j1; ++j) {
-          const unsigned int key = (unsigned int)(i * H + j) + 1u;
-          unsigned int h = (key * 0x9E3779B1u) >> 8 & mask;
-          for (int guard = 0; guard < g.bmw; ++guard) {
-            const unsigned int old = atomicCAS(&L.bm[h], 0u, key);
-            if (old == 0u || old == key) break;
-            h = (h + 1u) & mask;
-          }
-        }
-    }
-    return any_wide;
-  }
   for (int k = lane; k < N; k += WAVE) {
     const int cx = L.ncx[k], cy = L.ncy[k], u = L.nu[k];
     const int i1 = min(cx + u + 1, W), j1 = min(cy + u + 1, H);
@@ -815,7 +774,6 @@ __device__ __forceinline__ bool dyn_bitmap(const d2d_cfg &c, int lane, const Geo
         atomicOr(&L.bm[bit >> 5], 1u << (bit & 31));
       }
   }
-  return false;
 }
 
 // 3 x 3 cells (bit q = (di + 1) * 3 + (dj + 1)) of a block of half-width u in {0, 1} that lie inside the grid
@@ -827,6 +785,9 @@ __device__ __forceinline__ unsigned int block_valid9(int cx, int cy, int u, int 
   return r9 & (cols | (cols << 3) | (cols << 6));
 }
 
+// PREV / NEW: which of the two blocks are fetched (both for the one-pass update; the two-phase update of large grids fetches the
+// previous block before its first phase and the new block, again, after the fence between the phases).
+template <bool PREV = true, bool NEW = true>
 __device__ __forceinline__ void dyn_load(const d2d_cfg &c, const unsigned char *__restrict__ gt, int k, const LdsView &L,
                                          DynCells &dc) {
   const int W = c.W, H = c.H;
@@ -842,15 +803,15 @@ __device__ __forceinline__ void dyn_load(const d2d_cfg &c, const unsigned char *
 #pragma unroll
     for (int q = 0; q < 9; ++q) {
       const int o = (q / 3 - 1) * H + (q % 3 - 1);
-      pv[q] = pp[o];
-      nv[q] = np[o];
+      pv[q] = PREV ? pp[o] : (unsigned char)0;
+      nv[q] = NEW ? np[o] : (unsigned char)D2D_OCCUPIED;
     }
   } else {
 #pragma unroll
     for (int q = 0; q < 9; ++q) {  // clamped (always valid) addresses
       const int di = q / 3 - 1, dj = q % 3 - 1;
-      pv[q] = gt[min(max(pcx + di, 0), W - 1) * H + min(max(pcy + dj, 0), H - 1)];
-      nv[q] = gt[min(max(ncx + di, 0), W - 1) * H + min(max(ncy + dj, 0), H - 1)];
+      pv[q] = PREV ? gt[min(max(pcx + di, 0), W - 1) * H + min(max(pcy + dj, 0), H - 1)] : (unsigned char)0;
+      nv[q] = NEW ? gt[min(max(ncx + di, 0), W - 1) * H + min(max(ncy + dj, 0), H - 1)] : (unsigned char)D2D_OCCUPIED;
     }
   }
   unsigned int pdyn = 0, nfree = 0;
@@ -874,59 +835,64 @@ __device__ __forceinline__ void dyn_load(const d2d_cfg &c, const unsigned char *
   dc.nfree = small ? (nfree & block_valid9(ncx, ncy, nu, W, H)) : 0u;
 }
 
-template <bool FAST>
+// PHASE 0: the one-pass update (coverage from the LDS bitmap).
+// PHASE 1 / 2: the two-phase update of grids too large for a bitmap (Geom.dyn2p).  Phase 1: every agent clears the cells of its
+// previous block that hold DYNAMIC and lie outside its OWN new block -- whether or not another agent's new block covers them.
+// After a fence, phase 2: every agent fetches its new block again and marks what is neither static nor DYNAMIC, which restores
+// whatever a neighbour cleared in phase 1.  Same final grid as the reference's clear-everything-then-mark (a cell that is not
+// static ends DYNAMIC iff some new block covers it, and a cell that held DYNAMIC and is covered by nobody lies in a previous
+// block whose owner clears it), with no coverage structure: no LDS, no inserts, no lookups.
+template <int PHASE>
 __device__ __forceinline__ void dyn_apply(const d2d_cfg &c, const d2d_state &s, int e, int k, const Geom &g,
-                                          const LdsView &L, unsigned char *__restrict__ gt, const DynCells &dc, bool any_wide) {
+                                          const LdsView &L, unsigned char *__restrict__ gt, const DynCells &dc) {
   const int N = c.N, W = c.W, H = c.H;
   int *prev = s.dyn_prev + (size_t)e * N * 3;
-  const bool use_bm = g.bmw > 0 && !g.bmhash;
   const int pcx = L.pcx[k], pcy = L.pcy[k], pu = L.pu[k], ncx = L.ncx[k], ncy = L.ncy[k], nu = L.nu[k];
   auto covered = [&](int i, int j) {
+    if (PHASE == 1) return abs(i - ncx) <= nu && abs(j - ncy) <= nu;  // only the agent's own new block holds a clear back
     const int bit = i * H + j;
-    if (g.bmhash) {
-      const unsigned int mask = (unsigned int)g.bmw - 1u, key = (unsigned int)bit + 1u;
-      unsigned int h = (key * 0x9E3779B1u) >> 8 & mask;
-      bool found = false;
-      for (int guard = 0; guard < g.bmw; ++guard) {
-        const unsigned int v = L.bm[h];
-        if (v == key) found = true;
-        if (v == key || v == 0u) break;
-        h = (h + 1u) & mask;
-      }
-      return found || (any_wide && dyn_covered_wide(L, N, i, j));  // blocks wider than 3 x 3 are not in the set
-    }
-    return use_bm ? ((L.bm[bit >> 5] >> (bit & 31)) & 1u) != 0u : dyn_covered_loop(L, N, i, j);
+    return ((L.bm[bit >> 5] >> (bit & 31)) & 1u) != 0u;
   };
-  if (FAST && pu <= 1 && nu <= 1) {
+  if (pu <= 1 && nu <= 1) {
     // only set bits cost anything: none for an agent that stayed in its cell, a handful when it moved on
-    unsigned int m = dc.pclr;
-    while (m) {
-      const int q = __ffs((int)m) - 1;
-      m &= m - 1;
-      const int i = pcx + q / 3 - 1, j = pcy + q % 3 - 1;
-      if (!covered(i, j)) gt[i * H + j] = D2D_UNOCCUPIED;
+    if (PHASE != 2) {
+      unsigned int m = dc.pclr;  // already without the cells of the own new block
+      while (m) {
+        const int q = __ffs((int)m) - 1;
+        m &= m - 1;
+        const int i = pcx + q / 3 - 1, j = pcy + q % 3 - 1;
+        if (PHASE == 1 || !covered(i, j)) gt[i * H + j] = D2D_UNOCCUPIED;
+      }
     }
-    m = dc.nfree;
-    while (m) {
-      const int q = __ffs((int)m) - 1;
-      m &= m - 1;
-      gt[(ncx + q / 3 - 1) * H + (ncy + q % 3 - 1)] = D2D_DYNAMIC;
+    if (PHASE != 1) {
+      unsigned int m = dc.nfree;
+      while (m) {
+        const int q = __ffs((int)m) - 1;
+        m &= m - 1;
+        gt[(ncx + q / 3 - 1) * H + (ncy + q % 3 - 1)] = D2D_DYNAMIC;
+      }
     }
   } else {
-    const int i1 = min(pcx + pu + 1, W), j1 = min(pcy + pu + 1, H);
-    for (int i = max(pcx - pu, 0); i < i1; ++i)
-      for (int j = max(pcy - pu, 0); j < j1; ++j)
-        if (gt[i * H + j] == D2D_DYNAMIC && !covered(i, j)) gt[i * H + j] = D2D_UNOCCUPIED;
-    const int i3 = min(ncx + nu + 1, W), j3 = min(ncy + nu + 1, H);
-    for (int i = max(ncx - nu, 0); i < i3; ++i)
-      for (int j = max(ncy - nu, 0); j < j3; ++j) {
-        const unsigned char v = gt[i * H + j];
-        if (v != D2D_OCCUPIED && v != D2D_DYNAMIC) gt[i * H + j] = D2D_DYNAMIC;
-      }
+    if (PHASE != 2) {
+      const int i1 = min(pcx + pu + 1, W), j1 = min(pcy + pu + 1, H);
+      for (int i = max(pcx - pu, 0); i < i1; ++i)
+        for (int j = max(pcy - pu, 0); j < j1; ++j)
+          if (gt[i * H + j] == D2D_DYNAMIC && !covered(i, j)) gt[i * H + j] = D2D_UNOCCUPIED;
+    }
+    if (PHASE != 1) {
+      const int i3 = min(ncx + nu + 1, W), j3 = min(ncy + nu + 1, H);
+      for (int i = max(ncx - nu, 0); i < i3; ++i)
+        for (int j = max(ncy - nu, 0); j < j3; ++j) {
+          const unsigned char v = gt[i * H + j];
+          if (v != D2D_OCCUPIED && v != D2D_DYNAMIC) gt[i * H + j] = D2D_DYNAMIC;
+        }
+    }
   }
-  if (pcx != ncx) prev[3 * k] = ncx;
-  if (pcy != ncy) prev[3 * k + 1] = ncy;
-  if (pu != nu) prev[3 * k + 2] = nu;
+  if (PHASE != 1) {
+    if (pcx != ncx) prev[3 * k] = ncx;
+    if (pcy != ncy) prev[3 * k + 1] = ncy;
+    if (pu != nu) prev[3 * k + 2] = nu;
+  }
 }
 
 
@@ -1358,7 +1324,7 @@ __device__ __forceinline__ void run_env(const d2d_cfg &c, const d2d_state &s, in
   const int edge = (c.L - 1) / 2;
   const Tile wt = make_tile(ocx - g.reach, ocy - g.reach, g.ws, g.ws);
   const Tile ct = make_tile(ncx_d - edge, ncy_d - edge, c.L, c.L);
-  bool probe_wall = false, any_wide = false;
+  bool probe_wall = false;
   const bool dyn_fast = do_dyn;  // lane = agent, 64 agents per pass: the first pass's cells are fetched early (below), behind the raycast
   DynCells dc;
   dc.pclr = dc.nfree = 0;
@@ -1381,8 +1347,11 @@ __device__ __forceinline__ void run_env(const d2d_cfg &c, const d2d_state &s, in
       if (do_ray) tile_load<9>(wt, (unsigned char *)L.gtw, gt, W, H, lane, (unsigned char)D2D_OCCUPIED);
       if (do_obs) tile_load<9>(ct, (unsigned char *)L.dmt, dm, W, H, lane, (unsigned char)0);
     }
-    if (do_dyn) any_wide = dyn_bitmap(c, lane, g, L);
-    if (dyn_fast && lane < N) dyn_load(c, gt, lane, L, dc);
+    if (do_dyn) dyn_bitmap(c, lane, g, L);
+    if (dyn_fast && lane < N) {
+      if (g.dyn2p) dyn_load<true, false>(c, gt, lane, L, dc);
+      else dyn_load(c, gt, lane, L, dc);
+    }
   }
 
   // ---------------- raycast: setup while the loads are in flight ----------------
@@ -1494,14 +1463,27 @@ __device__ __forceinline__ void run_env(const d2d_cfg &c, const d2d_state &s, in
   if (do_dyn) {
     if constexpr (FULL) {
       dyn_full(c, s, e, lane, L, gt);
+    } else if (g.dyn2p) {  // grids above 256 x 256 cells: clear, fence, fetch again and mark (dyn_apply)
+      if (lane < N) dyn_apply<1>(c, s, e, lane, g, L, gt, dc);
+      for (int k = WAVE + lane; k < N; k += WAVE) {
+        DynCells dk;
+        dyn_load<true, false>(c, gt, k, L, dk);
+        dyn_apply<1>(c, s, e, k, g, L, gt, dk);
+      }
+      wave_sync_global();
+      for (int k = lane; k < N; k += WAVE) {
+        DynCells dk;
+        dyn_load<false, true>(c, gt, k, L, dk);
+        dyn_apply<2>(c, s, e, k, g, L, gt, dk);
+      }
     } else {
-      if (lane < N) dyn_apply<true>(c, s, e, lane, g, L, gt, dc, any_wide);
+      if (lane < N) dyn_apply<0>(c, s, e, lane, g, L, gt, dc);
       // more than 64 agents: every further pass fetches the 18 cells of its 64 agents together (one round trip), then applies.
       // A later pass may read cells an earlier one has already written: the rule is order-independent (see dyn_apply).
       for (int k = WAVE + lane; k < N; k += WAVE) {
         DynCells dk;
         dyn_load(c, gt, k, L, dk);
-        dyn_apply<true>(c, s, e, k, g, L, gt, dk, any_wide);
+        dyn_apply<0>(c, s, e, k, g, L, gt, dk);
       }
     }
   }
