@@ -66,13 +66,31 @@ def _cfg_default_geometry(rng):
     return kw
 
 
+def _cfg_large_grid(rng):
+    """Grids above 256 x 256 cells: no LDS coverage bitmap, the dynamic-grid update runs in two phases; several lane passes of
+    rays; agents of one to 5 x 5 cells, slow to fast, sometimes bunched around the drone."""
+    w, h = (int(v) for v in rng.choice([2600, 2900, 3300, 4100], 2))
+    kw = dict(agent_number=int(rng.choice([3, 20, 64, 65, 100, 130])), agent_radius=int(rng.choice([-1, 5, 12, 15, 25])),
+              agent_max_speed=int(rng.choice([10, 40, 60])), map_id=int(rng.randint(0, 100000)), map_size=[w, h],
+              drone_view_range=int(rng.choice([60, 90, 120])), drone_view_depth=int(rng.choice([60, 80, 120])))
+    kw['init_pos'] = [int(rng.randint(200, w - 200)), int(rng.randint(200, h - 200))]
+    kw['target_list'] = [[int(rng.randint(40, w - 40)), int(rng.randint(40, h - 40))]]
+    return kw
+
+
+N_LARGE = max(6, N_SEEDS // 5)
+
+
 @pytest.mark.parametrize('family,seed', [('any', s) for s in list(range(SEED_BASE, SEED_BASE + N_SEEDS)) +
                                          (REGRESSION_SEEDS if SEED_BASE == 0 else [])] +
-                         [('default', s) for s in range(SEED_BASE, SEED_BASE + N_SEEDS)])
+                         [('default', s) for s in range(SEED_BASE, SEED_BASE + N_SEEDS)] +
+                         [('large', s) for s in range(SEED_BASE, SEED_BASE + N_LARGE)])
 def test_random_step_matches_oracle(pkg, hip, oracle, family, seed):
-    rng = np.random.RandomState((7000 if family == 'any' else 57000) + seed)
-    kw = _cfg(rng) if family == 'any' else _cfg_default_geometry(rng)
+    rng = np.random.RandomState({'any': 7000, 'default': 57000, 'large': 107000}[family] + seed)
+    kw = {'any': _cfg, 'default': _cfg_default_geometry, 'large': _cfg_large_grid}[family](rng)
     B, T = int(rng.choice([2, 5, 9])), 24
+    if family == 'large':
+        B, T = int(rng.choice([2, 3])), 10
     external = bool(rng.rand() < 0.5)
     r2 = np.random.RandomState(900000 + seed)          # drawn apart so that the configurations above keep their seeds
     mode = str(r2.choice(['fused', 'fused', 'split', 'stages']))   # device entry points; the oracle always runs the fused step
@@ -80,6 +98,14 @@ def test_random_step_matches_oracle(pkg, hip, oracle, family, seed):
         kw['var_cam'] = int(r2.choice([1, 2]))          # measurement noise: the draws are an input (utils.py:605)
     dev, ref = _pair(pkg, hip, oracle, B, planner='Primitive' if external else 'NoMove', **kw)
     W, H = dev.cfg.W_px, dev.cfg.H_px
+    if family == 'large' and rng.rand() < 0.6:    # bunch the agents around the drone: overlapping blocks, ray hits
+        from drone2d_amd import _abi as A
+        ag = ref.state.agents.clone()
+        x0, y0 = kw['init_pos']
+        ag[:, A.A_PX] = torch.from_numpy(rng.uniform(x0 - 150, x0 + 150, tuple(ag[:, A.A_PX].shape)))
+        ag[:, A.A_PY] = torch.from_numpy(rng.uniform(y0 - 150, y0 + 150, tuple(ag[:, A.A_PY].shape)))
+        for env in (dev, ref):
+            env.state.agents.copy_(ag)
     for t in range(T):
         a = rng.uniform(-1, 1, B)
         if rng.rand() < 0.2:       # teleport, sometimes right onto the border cells

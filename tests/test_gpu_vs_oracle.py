@@ -378,3 +378,33 @@ def test_many_agent_raycast_candidates_at_the_cone_edges(pkg, hip, oracle):
         ref.step(a)
         _assert_same(dev, ref, f'crowd step {t + 1}')
     assert int(ref.state.hit.sum(1).min()) >= 6
+
+
+@pytest.mark.parametrize('radius,speed', [(12, 60), (25, 40)])
+def test_two_phase_dynamic_grid_with_packed_agents(pkg, hip, oracle, radius, speed):
+    """Grids above 256 x 256 cells update the dynamic cells in two phases (csrc dyn_apply<1> / <2>: every agent clears what its
+    previous block leaves behind, fence, every agent fetches its new block again and marks) instead of asking a coverage
+    structure.  90 fast agents (two lane passes) packed into a 260 x 260 px corner of a 3000 x 3000 px map, so that blocks overlap
+    and neighbours keep clearing cells of each other's new blocks -- 3 x 3 blocks (radius 12) and 5 x 5 blocks (radius 25, the
+    general loops): the ground truth equals the oracle's literal clear-all-then-mark (utils.py:527-540) for 20 steps."""
+    from drone2d_amd import _abi as A
+    B, N = 6, 90
+    dev, ref = _pair(pkg, hip, oracle, B, agent_number=N, agent_radius=radius, agent_max_speed=speed, map_id=5,
+                     map_size=[3000, 3000], init_pos=[400, 400], target_list=[[2500, 2500]])
+    assert dev.cfg.W == 300 and dev.cfg.N == N
+    rng = np.random.RandomState(radius)
+    ag = ref.state.agents.clone()
+    ag[:, A.A_PX] = torch.from_numpy(rng.uniform(120, 380, (B, N)))
+    ag[:, A.A_PY] = torch.from_numpy(rng.uniform(120, 380, (B, N)))
+    for env in (dev, ref):
+        env.state.agents.copy_(ag)
+    moved = 0
+    for t in range(20):
+        a = rng.uniform(-1, 1, B)
+        before = ref.state.dyn_prev.clone()
+        dev.step(a)
+        ref.step(a)
+        _assert_same(dev, ref, f'packed agents r={radius} step {t + 1}')
+        moved += int((before[:, :, :2] != ref.state.dyn_prev[:, :, :2]).any(2).sum())
+    assert moved > 20 * B * N // 6                                  # blocks really change cell all the time
+    assert int((ref.state.gt == A.DYNAMIC).sum()) > B * 200
