@@ -1518,7 +1518,7 @@ __host__ __device__ constexpr int spec_ncap(int spec) { return spec == 1 ? 16 : 
 // then stays below 10 KB, four 4-wave workgroups per CU).  With more agents the per-agent planes already fill the LDS and
 // 5 KB more per wave cost occupancy in the persistent loop -- measured on BASELINE config 4 (24 agents): 4.9e7 env-steps/s
 // with whole grids against 5.5e7 with the window / crop tiles; config 3 (172 agents): 8 -> 6 waves per CU, the step 35 % slower.
-__host__ __device__ constexpr bool spec_full(int spec) { return spec == 1; }
+__host__ __device__ constexpr bool spec_full(int spec) { return spec == 1 || spec == 2; }
 // 64 ray candidates on the mask path instead of 32: the default geometry with more than 32 agents (BASELINE config 3: 172 agents
 // on 500 x 500 px).  Not the generic kernel: it is at its scalar-register limit (the per-lane predicates of the march live in
 // SGPR pairs) and the wider mask costs config 5 -- 100 agents on 6400 x 6400 px, hardly ever a candidate -- a quarter of its
