@@ -9,7 +9,7 @@
 //                                      ground-truth window the rays can reach is an LDS tile
 //   collision                        : lane = probe / agent, __any / __ballot reduction
 //   observation                      : an LDS tile of the drone's map that the rays patch in place
-// Memory schedule of one env-step, default geometry with N <= 16 (SPEC 1, Geom.full) -- ONE batch of loads, then fire-and-forget
+// Memory schedule of one env-step, default geometry with N <= 32 (SPEC 1 / 2, Geom.full) -- ONE batch of loads, then fire-and-forget
 // stores, no fence:
 //   batch    everything is addressed by the env index alone: pose, counters, inputs, agents, tracker flags; the tracker states
 //            and BOTH 50 x 50 grids go to LDS whole by LDS-DMA (global_load_lds, no VGPRs).  Rays, collision probes, the
@@ -18,7 +18,9 @@
 //   stores   agents, drone map, grid, trackers, flags, observation
 // Other configurations (more agents, other maps) keep two batches: batch 2 = the ground-truth window tile the rays can reach
 // and the drone-map crop tile (byte loads, all in flight before the first LDS write), dynamic-grid cells, collision probes,
-// all addressed by batch-1 data.
+// all addressed by batch-1 data.  Their kernels (SPEC 3 = default geometry with any number of agents, SPEC 0 = anything) read
+// cfg / state through the kernarg segment (StagesKArgs), cull ray candidates against the cone of the rays, and update the
+// dynamic cells of grids above 256 x 256 cells in two phases (dyn_apply).
 // What bounds the kernel is instruction issue (~1400 VALU + ~950 SALU wave-instructions per env-step at config 2, fp64
 // heavy), not bytes: see DESIGN.md section 3 for the measurements behind each choice.
 // The planner / gaze plugins (d2d_plugins.h) and the persistent closed loop k_closed (every wave loops over the steps
