@@ -135,4 +135,16 @@ def test_bench_workload_keeps_four_workgroups_per_cu(pkg):
     # config 3's agent count (172) on the default geometry: one or two waves per workgroup, still the specialised kernels
     cfg3 = host_init.derive_cfg(p, B=16, N=172, T=1, planner_mode=pkg._abi.PLANNER_EXTERNAL, kf_enabled=True)
     wpb3, lds3, per_cu3, spec3 = _lib.launch_shape(cfg3)
-    assert wpb3 >= 1 and spec3 == 0 and wpb3 * per_cu3 >= 6      # many agents: tiles, not whole grids (8 waves per CU at wpb 2)
+    assert wpb3 >= 1 and spec3 == 0 and wpb3 * per_cu3 >= 12     # many agents: tiles, not whole grids; 12 waves per CU (50 B per
+    #                                                               agent, at most 64 ray candidates; 8 at 98 B per agent)
+    # config 4's agent count (24): whole grids like config 2, 16 waves per CU
+    cfg4 = host_init.derive_cfg(p, B=16, N=24, T=1, planner_mode=pkg._abi.PLANNER_EXTERNAL, kf_enabled=True)
+    wpb4, lds4, per_cu4, spec4 = _lib.launch_shape(cfg4)
+    assert (wpb4, spec4) == (4, 1) and per_cu4 >= 4
+    # config 5 (100 agents on 640 x 640 cells, 640 rays): the generic kernel within the 10 KB per wave that keep 16 waves on a
+    # CU -- the dynamic-grid update of a grid that large needs no LDS structure (two phases)
+    p5 = pkg.with_defaults(pkg.Params(planner='NoMove', agent_number=100, agent_radius=15, agent_max_speed=40, drone_max_speed=40,
+                                      map_size=[6400, 6400], init_pos=[3200, 3200], target_list=[[6000, 6000]]))
+    cfg5 = host_init.derive_cfg(p5, B=16, N=100, T=1, planner_mode=pkg._abi.PLANNER_NOMOVE, kf_enabled=True)
+    wpb5, lds5, per_cu5, spec5 = _lib.launch_shape(cfg5)
+    assert spec5 == 0 and wpb5 * per_cu5 >= 16 and lds5 <= 4 * 10240, (wpb5, lds5, per_cu5)
