@@ -126,7 +126,7 @@ typedef struct d2d_cfg {
   int32_t abi_version; /* D2D_ABI_VERSION */
   int32_t B;           /* envs in this shard */
   int32_t N;           /* agents per env: agent_number + nonzero cells of the static map (drone_v2.py:28-66) */
-  int32_t W, H;        /* map_size // map_scale (utils.py:497-498) */
+  int32_t W, H;        /* map_size // map_scale (utils.py:497-498); at most 32767 cells a side (-4 otherwise) */
   int32_t R;           /* rays = ceil(map_size[0] / 10) (utils.py:570,587) */
   int32_t L;           /* local map edge = 4 * (view_depth // map_scale) + 1 (drone_v2.py:133) */
   int32_t T;           /* capacity of the per-env target list */

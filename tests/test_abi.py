@@ -74,6 +74,9 @@ def test_argument_validation_without_gpu(pkg):
     c.scale, c.depth, c.dt = 1.0, 80.0, 0.1
     assert fn['step'](C.byref(c), C.byref(s), None) == -4 and b'map_scale' in fn['last_error']()
     c.scale = 10.0
+    c.W = 40000                                                              # 16-bit cell planes in LDS: at most 32767 cells a side
+    assert fn['step'](C.byref(c), C.byref(s), None) == -4 and b'32767' in fn['last_error']()
+    c.W = 50
     assert fn['step'](C.byref(c), C.byref(s), None) == -1 and b'null' in fn['last_error']()
     assert fn['tan_array'](None, None, 5, None) == -1
     assert fn['sincos_array'](None, None, None, 5, None) == -1
