@@ -1722,6 +1722,10 @@ __device__ __attribute__((noinline)) int ph_plan_quick(const ClosedArgs *ap, int
   char *base = d2d_lds + __builtin_amdgcn_readfirstlane(lds_off_);
   d2d_cfg c = a->c;
   if (SPEC != 0) spec_default_apply(c);
+  if constexpr (SPEC == 1 || SPEC == 2) {  // folds the size of the search's cost mirror (search_lds_nodes)
+    constexpr int cap = spec_ncap(SPEC);
+    __builtin_assume(c.N <= cap);
+  }
   const bool need = plan_env_quick(c, a->s, a->p, e, lane, base);
   wave_sync_global();
   return need ? 1 : 0;
@@ -1734,6 +1738,10 @@ __device__ __attribute__((noinline)) void ph_plan_search(const ClosedArgs *ap, i
   char *base = d2d_lds + __builtin_amdgcn_readfirstlane(lds_off_);
   d2d_cfg c = a->c;
   if (SPEC != 0) spec_default_apply(c);
+  if constexpr (SPEC == 1 || SPEC == 2) {  // folds the size of the search's cost mirror (search_lds_nodes)
+    constexpr int cap = spec_ncap(SPEC);
+    __builtin_assume(c.N <= cap);
+  }
   plan_env_search(c, a->s, a->p, e, lane, base);
   wave_sync_global();
 }

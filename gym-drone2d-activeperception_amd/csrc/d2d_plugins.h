@@ -83,7 +83,7 @@ __device__ __forceinline__ int wave_argmin(double t, int idx) {
 
 struct TrkView {  // active trackers of the env, compacted into LDS
   double *mx, *my, *vx, *vy;
-  double *lim_plan, *lim_replan;  // norm(d) <= L rewritten as d.d <= T(L), see sq_threshold
+  double *lim;  // norm(d) <= L rewritten as d.d <= T(L), see sq_threshold: replan_check's limits, then (when a search follows) plan's
   int n;
 };
 
@@ -111,7 +111,7 @@ __device__ __forceinline__ bool plan_hits_round(const TrkView &T, int q, double 
   double mx[WIDTH], my[WIDTH], vx[WIDTH], vy[WIDTH], lim[WIDTH];
 #pragma unroll
   for (int u = 0; u < WIDTH; ++u) {
-    mx[u] = T.mx[q + u]; my[u] = T.my[q + u]; vx[u] = T.vx[q + u]; vy[u] = T.vy[q + u]; lim[u] = T.lim_plan[q + u];
+    mx[u] = T.mx[q + u]; my[u] = T.my[q + u]; vx[u] = T.vx[q + u]; vy[u] = T.vy[q + u]; lim[u] = T.lim[q + u];
   }
   bool hit = false;
 #pragma unroll
@@ -249,11 +249,14 @@ struct SearchLds {
   long long *rk;    // [64] de-duplication keys
   int *ri;          // [64] reduction indices
   int *misc;        // [4] misc[0] = number of active trackers staged by the quick part of the stage
-  double *tot;      // [D2D_SEARCH_LDS_NODES] total_cost of the first nodes, +inf once closed (the min() scan reads these)
+  double *tot;      // [ntot] total_cost of the first nodes, +inf once closed (the min() scan reads these)
+  int ntot;         // search_lds_nodes(N)
   unsigned char *map;  // [W * H] copy of the explored map for the collision probes, or null when it does not fit
 };
 
-#define D2D_SEARCH_LDS_NODES 512
+// nodes whose total_cost is mirrored in LDS: 512 (a capped search makes about 800); with more than 64 agents the six-plane
+// tracker staging grows and 256 keep the planner stage within three 4-wave workgroups per CU (BASELINE config 3: 13.4 KB per wave)
+__host__ __device__ inline int search_lds_nodes(int N) { return N > 64 ? 256 : 512; }
 #define D2D_SEARCH_LDS_MAP 4096
 
 // Primitive.plan's search (traj_planner.py:128-218) by one wave.  Returns the number of waypoints written, -1 = failure.
@@ -340,13 +343,13 @@ __device__ int plan_search(const d2d_cfg &c, const d2d_state &s, const d2d_plan 
     int bidx = 0x7fffffff;
     bool fenced = false;
     {
-      // the first D2D_SEARCH_LDS_NODES nodes from their LDS mirror (closed = +inf; an open node with an infinite or
+      // the first S.ntot nodes from their LDS mirror (closed = +inf; an open node with an infinite or
       // NaN cost is told apart by the state plane below, which such a search then falls back to)
-      const int nl = min(nn, D2D_SEARCH_LDS_NODES);
+      const int nl = min(nn, S.ntot);
       for (int s0 = 0; s0 < nl; s0 += 4 * WAVE) {
         double t4[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) t4[u] = S.tot[min(s0 + u * WAVE + lane, D2D_SEARCH_LDS_NODES - 1)];
+        for (int u = 0; u < 4; ++u) t4[u] = S.tot[min(s0 + u * WAVE + lane, S.ntot - 1)];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const int si = s0 + u * WAVE + lane;
@@ -396,7 +399,7 @@ __device__ int plan_search(const d2d_cfg &c, const d2d_state &s, const d2d_plan 
     }
     if (lane == 0) {
       nd.state[cur] = 2;
-      if (cur < D2D_SEARCH_LDS_NODES) S.tot[cur] = kInf;
+      if (cur < S.ntot) S.tot[cur] = kInf;
     }
     open_n -= 1;
     expansions += 1;
@@ -618,7 +621,7 @@ __device__ int plan_search(const d2d_cfg &c, const d2d_state &s, const d2d_plan 
         nd.cost[gslot] = cost;
         const double tot = cost + 0.5 * norm2(ex - tx, ey - ty) + 0.1 * norm2(vex, vey);
         nd.total[gslot] = tot;
-        if (gslot < D2D_SEARCH_LDS_NODES) S.tot[gslot] = tot;
+        if (gslot < S.ntot) S.tot[gslot] = tot;
         nd.ax[gslot] = ax; nd.ay[gslot] = ay;
         nd.link[gslot] = make_int2(cur, citr + 1);
         nd.key[gslot] = key;
@@ -713,7 +716,7 @@ __host__ __device__ inline int plan_wave_bytes(int N, int nu, int n_sample, int 
   const int ncap = ((N > 0 ? N : 1) + 3) & ~3;
   const int nu4 = (nu + 3) & ~3, ns4 = (2 * n_sample + 3) & ~3;
   const int mapb = WH <= D2D_SEARCH_LDS_MAP ? ((WH + 15) & ~15) : 0;
-  return 6 * 8 * ncap + 8 * (nu4 + ns4) + 8 * 64 + 8 * 64 + 4 * 64 + 128 * 4 + 16 + 8 * D2D_SEARCH_LDS_NODES + mapb;
+  return 5 * 8 * ncap + 8 * (nu4 + ns4) + 8 * 64 + 8 * 64 + 4 * 64 + 128 * 4 + 16 + 8 * search_lds_nodes(N) + mapb;
 }
 
 // replan_check + plan + head waypoint of env e by one wave; `base`: plan_wave_bytes() bytes of LDS
@@ -723,9 +726,8 @@ __device__ __forceinline__ void plan_carve(const d2d_cfg &c, const d2d_plan &p, 
   T.my = T.mx + ncap;
   T.vx = T.my + ncap;
   T.vy = T.vx + ncap;
-  T.lim_plan = T.vy + ncap;
-  T.lim_replan = T.lim_plan + ncap;
-  S.us = T.lim_replan + ncap;
+  T.lim = T.vy + ncap;
+  S.us = T.lim + ncap;
   S.st = S.us + ((p.nu + 3) & ~3);
   S.rv = S.st + ((2 * p.n_sample + 3) & ~3);
   S.rk = (long long *)(S.rv + 64);
@@ -733,7 +735,8 @@ __device__ __forceinline__ void plan_carve(const d2d_cfg &c, const d2d_plan &p, 
   S.chain = S.ri + 64;
   S.misc = S.chain + 128;
   S.tot = (double *)(S.misc + 4);
-  S.map = (c.W * c.H <= D2D_SEARCH_LDS_MAP) ? (unsigned char *)(S.tot + D2D_SEARCH_LDS_NODES) : nullptr;
+  S.ntot = search_lds_nodes(N);
+  S.map = (c.W * c.H <= D2D_SEARCH_LDS_MAP) ? (unsigned char *)(S.tot + S.ntot) : nullptr;
 }
 
 // Writes the head step_pos will consume (utils.py:733-739) and the planner's result; pops the head.
@@ -799,9 +802,7 @@ __device__ __forceinline__ bool plan_env_quick(const d2d_cfg &c, const d2d_state
     if (act) {
       const int q = nact + __popcll(am & ((1ull << lane) - 1ull));
       T.mx[q] = m0; T.my[q] = m1; T.vx[q] = m2; T.vy[q] = m3;
-      T.lim_plan[q] = c.drone_radius + rad + 5 + c.sigma;  // traj_planner.py:58: the limit itself; only a search needs its
-                                                           // squared threshold (plan_env_search), a few percent of the steps
-      T.lim_replan[q] = lim2;                                             // traj_planner.py:228, cached threshold (see below)
+      T.lim[q] = lim2;  // traj_planner.py:228, cached threshold (see above); a search replaces it with its own (below)
     }
     nact += __popcll(am);
   }
@@ -829,7 +830,7 @@ __device__ __forceinline__ bool plan_env_quick(const d2d_cfg &c, const d2d_state
           double mx[4], my[4], vx[4], vy[4], lim[4];
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
-            mx[u] = T.mx[q + u]; my[u] = T.my[q + u]; vx[u] = T.vx[q + u]; vy[u] = T.vy[q + u]; lim[u] = T.lim_replan[q + u];
+            mx[u] = T.mx[q + u]; my[u] = T.my[q + u]; vx[u] = T.vx[q + u]; vy[u] = T.vy[q + u]; lim[u] = T.lim[q + u];
           }
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
@@ -843,6 +844,16 @@ __device__ __forceinline__ bool plan_env_quick(const d2d_cfg &c, const d2d_state
     if (__any(bad)) head = stored = 0;
   }
   if (stored - head == 0) {  // Primitive.plan has to search: the trackers (and their count) wait in LDS
+    // ... with the limit of Planner.is_free in the one limit plane (traj_planner.py:58: drone_radius + radius + 5 + var_cam, as
+    // its squared threshold): the same compaction walk as above, a few percent of the steps
+    int q0 = 0;
+    for (int k0 = 0; k0 < N; k0 += WAVE) {
+      const int k = k0 + lane;
+      const bool act = k < N && s.active[(size_t)e * N + k] != 0;
+      const unsigned long long am = __ballot(act);
+      if (act) T.lim[q0 + __popcll(am & ((1ull << lane) - 1ull))] = sq_threshold(c.drone_radius + p.trk_radius[(size_t)e * N + k] + 5 + c.sigma);
+      q0 += __popcll(am);
+    }
     if (lane == 0) {
       hdr[0] = 0;
       hdr[1] = 0;
@@ -860,9 +871,7 @@ __device__ __forceinline__ void plan_env_search(const d2d_cfg &c, const d2d_stat
   TrkView T;
   SearchLds S;
   plan_carve(c, p, base, T, S);
-  T.n = S.misc[0];  // the trackers are still in LDS
-  for (int q = lane; q < T.n; q += WAVE) T.lim_plan[q] = sq_threshold(T.lim_plan[q]);
-  wave_sync_lds();
+  T.n = S.misc[0];  // the trackers are still in LDS, the limit plane holds plan's thresholds (plan_env_quick)
   const double inv_scale = 1.0 / c.scale;
   const unsigned char *__restrict__ dm = s.dmap + (size_t)e * c.W * c.H;
   // A search is a long chain of short dependent steps and, in the persistent loop, what the slowest env of a launch
