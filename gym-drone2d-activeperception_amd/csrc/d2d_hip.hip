@@ -665,11 +665,12 @@ __device__ __forceinline__ void ray_march(const d2d_cfg &c, const Geom &g, const
   const double c1x = L.cx[q1], c1y = L.cy[q1], c1r2 = has1 ? L.cr2[q1] : -1.0;
   const int c1i = L.cidx[q1];
   const M rest = mask_path ? (M)(ry.cmask & (ry.cmask - (M)1)) : (M)0;
+  const bool some1 = __any(has1);
   auto sample = [&](auto far_tag) {
     constexpr bool FAR = decltype(far_tag)::value;
     // exact circle tests (utils.py:658-662): every candidate that can matter, no early-out among agents
     bool any = false;
-    {
+    if (some1) {  // wave-uniform: no ray of this pass has a candidate at all (the usual case on a sparse map) -> nothing to test
       const double dx = c1x - x, dy = c1y - y;
       any = alive && (dx * dx + dy * dy <= c1r2);
       if (any) L.hit[c1i] = 1;
