@@ -9,7 +9,7 @@
 //                                      ground-truth window the rays can reach is an LDS tile
 //   collision                        : lane = probe / agent, __any / __ballot reduction
 //   observation                      : an LDS tile of the drone's map that the rays patch in place
-// Memory schedule of one env-step, default geometry with N <= 32 (SPEC 1 / 2, Geom.full) -- ONE batch of loads, then fire-and-forget
+// Memory schedule of one env-step, default geometry with N <= 40 (SPEC 1 / 2, Geom.full) -- ONE batch of loads, then fire-and-forget
 // stores, no fence:
 //   batch    everything is addressed by the env index alone: pose, counters, inputs, agents, tracker flags; the tracker states
 //            and BOTH 50 x 50 grids go to LDS whole by LDS-DMA (global_load_lds, no VGPRs).  Rays, collision probes, the
@@ -1514,9 +1514,10 @@ __device__ __forceinline__ void run_env(const d2d_cfg &c, const d2d_state &s, in
 // rematerialise, and past ~100 of them it spills to VGPR lanes (v_readlane on every use).  Overwriting the
 // kernel's own copy of the config with the literals the host has verified turns them into immediates:
 // constant-folded tile sizes and LDS offsets, no spills.  Any other config takes the generic instantiation.
-// SPEC 1: N <= 16 agent slots, SPEC 2: N <= 32 (the default map plus the 14 obstacle_map agents), SPEC 3: the
+// SPEC 1: N <= 16 agent slots, SPEC 2: N <= 40 (the default map plus the 14 obstacle_map agents, the reference's sweeps of up
+// to 30 agents; 40 is where both grids whole + the agent planes still leave four workgroups per CU in every phase), SPEC 3: the
 // default geometry with any N (LDS capacity and waves per workgroup stay run-time values)
-__host__ __device__ constexpr int spec_ncap(int spec) { return spec == 1 ? 16 : (spec == 2 ? 32 : 0); }
+__host__ __device__ constexpr int spec_ncap(int spec) { return spec == 1 ? 16 : (spec == 2 ? 40 : 0); }
 // Both grids staged whole in LDS (Geom.full) only for the instantiation with few agents (N <= 16: the per-wave working set
 // then stays below 10 KB, four 4-wave workgroups per CU).  With more agents the per-agent planes already fill the LDS and
 // 5 KB more per wave cost occupancy in the persistent loop -- measured on BASELINE config 4 (24 agents): 4.9e7 env-steps/s
