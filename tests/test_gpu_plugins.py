@@ -228,9 +228,14 @@ def test_baseline_configs_closed_loop_at_full_size(pkg, hip, label, B, K, kw):
 @pytest.mark.parametrize('label,kw', [
     ('config3', dict(agent_number=50, agent_radius=10, agent_max_speed=40, static_map='maps/random_map_0.npy')),
     ('config4', dict(agent_number=10, agent_radius=15, agent_max_speed=20, static_map='maps/obstacle_map.npy')),
+    # the upper end of the whole-grid kernel (SPEC 2: up to 40 agents) and the first agent count past it, on the default geometry
+    ('n40', dict(agent_number=40, agent_radius=10, agent_max_speed=40)),
+    ('n26_obstacles', dict(agent_number=26, agent_radius=8, agent_max_speed=30, static_map='maps/obstacle_map.npy')),
+    ('n41', dict(agent_number=41, agent_radius=8, agent_max_speed=40)),
 ])
 def test_baseline_configs_closed_loop_vs_oracle(pkg, hip, oracle, label, kw):
-    """The same two configurations against the oracle: 6 seeded worlds, 80 closed-loop steps with auto reset, every field."""
+    """The same two configurations (and the agent counts around the whole-grid kernel's limit) against the oracle: 6 seeded worlds,
+    80 closed-loop steps with auto reset, every field."""
     dev, ref = _pair(pkg, hip, oracle, 6, drone_max_speed=40, map_id=1, **kw)
     for _ in range(2):
         dev.closed_loop(40, auto_reset=True)
