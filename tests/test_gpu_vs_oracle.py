@@ -408,3 +408,24 @@ def test_two_phase_dynamic_grid_with_packed_agents(pkg, hip, oracle, radius, spe
         moved += int((before[:, :, :2] != ref.state.dyn_prev[:, :, :2]).any(2).sum())
     assert moved > 20 * B * N // 6                                  # blocks really change cell all the time
     assert int((ref.state.gt == A.DYNAMIC).sum()) > B * 200
+
+
+def test_gathered_tracker_filters_with_many_agents(pkg, hip, oracle):
+    """More than 128 agents (three lane passes): the Kalman filters that have work -- active, or hit this step -- are gathered
+    into one list before they run (csrc st_tracker).  150 fast agents, the view sweeping round at full yaw rate for 60 steps so
+    that dozens of trackers start, update, coast without measurements and are archived: tracker state, lengths, active flags,
+    buffer counters and everything else equal the oracle's at every step."""
+    from drone2d_amd import _abi as A
+    B, N = 6, 150
+    dev, ref = _pair(pkg, hip, oracle, B, agent_number=N, agent_radius=6, agent_max_speed=40, map_id=17, init_pos=[250, 250],
+                     drone_max_speed=40)
+    assert dev.cfg.N == N
+    most, archived = 0, 0
+    for t in range(60):
+        a = np.full(B, 1.0 if (t // 20) % 2 == 0 else -0.6)
+        dev.step(a)
+        ref.step(a)
+        _assert_same(dev, ref, f'150 agents step {t + 1}')
+        most = max(most, int(ref.state.active.sum(1).max()))
+        archived = int(ref.state.counters[:, A.C_BUF_N].sum())
+    assert most >= 12 and archived > 0, (most, archived)
