@@ -245,6 +245,7 @@ struct SearchLds {
   int *chain;       // [128] path slots; during the search [0..63] = lane of the r-th valid primitive, [64..127] = its free count
   double *us;       // [nu] u_space
   double *st;       // [n_sample][2] t, t**2
+  double *pc;       // [nu * nu] (x_acc**2 + y_acc**2) / 100 of every primitive (traj_planner.py:184): one division per search, not per expansion
   double *rv;       // [64] reduction / de-duplication values (candidate costs)
   long long *rk;    // [64] de-duplication keys
   int *ri;          // [64] reduction indices
@@ -282,6 +283,15 @@ __device__ int plan_search(const d2d_cfg &c, const d2d_state &s, const d2d_plan 
   SP_T(spa);
   for (int i = lane; i < p.hash_cap; i += WAVE) tab[i] = 0;
   for (int i = lane; i < p.nu; i += WAVE) S.us[i] = p.u_space[i];
+  {
+    const FastDiv fdu(p.nu);
+    for (int i = lane; i < p.nu * p.nu; i += WAVE) {
+      int ia, ja;
+      fdu.divmod(i, ia, ja);
+      const double ax = p.u_space[ia], ay = p.u_space[ja];
+      S.pc[i] = (ax * ax + ay * ay) / 100;  // traj_planner.py:184
+    }
+  }
   for (int i = lane; i < 2 * p.n_sample; i += WAVE) S.st[i] = p.sample_t[i];
   const bool lds_map = S.map != nullptr;
   if (lds_map) {  // the whole explored map (2.5 KB at 50 x 50): every probe of the search comes from LDS
@@ -505,7 +515,7 @@ __device__ int plan_search(const d2d_cfg &c, const d2d_state &s, const d2d_plan 
       SP_T(sp4);
       SP_ADD(3, sp3, sp4);
       const double ex = rint((px + H * vx) + (H * H) * hx), ey = rint((py + H * vy) + (H * H) * hy);  // :182
-      const double cost = ccost + (ax * ax + ay * ay) / 100 + 10;                                     // :184
+      const double cost = ccost + S.pc[ok ? pi : 0] + 10;                                             // :184, the term from its table
       const long long key = node_key(ex, ey, vex, vey);
       // ---- :192-202 for all successors of the batch at once ----
       int slot = -1;
@@ -714,7 +724,7 @@ __device__ int plan_search(const d2d_cfg &c, const d2d_state &s, const d2d_plan 
 // LDS per wave of k_plan: 6 planes of ncap doubles (active trackers) + the search's hand-off arrays
 __host__ __device__ inline int plan_wave_bytes(int N, int nu, int n_sample, int WH) {
   const int ncap = ((N > 0 ? N : 1) + 3) & ~3;
-  const int nu4 = (nu + 3) & ~3, ns4 = (2 * n_sample + 3) & ~3;
+  const int nu4 = ((nu + 3) & ~3) + ((nu * nu + 3) & ~3), ns4 = (2 * n_sample + 3) & ~3;  // u_space + the primitives' cost terms
   const int mapb = WH <= D2D_SEARCH_LDS_MAP ? ((WH + 15) & ~15) : 0;
   return 5 * 8 * ncap + 8 * (nu4 + ns4) + 8 * 64 + 8 * 64 + 4 * 64 + 128 * 4 + 16 + 8 * search_lds_nodes(N) + mapb;
 }
@@ -728,7 +738,8 @@ __device__ __forceinline__ void plan_carve(const d2d_cfg &c, const d2d_plan &p, 
   T.vy = T.vx + ncap;
   T.lim = T.vy + ncap;
   S.us = T.lim + ncap;
-  S.st = S.us + ((p.nu + 3) & ~3);
+  S.pc = S.us + ((p.nu + 3) & ~3);
+  S.st = S.pc + ((p.nu * p.nu + 3) & ~3);
   S.rv = S.st + ((2 * p.n_sample + 3) & ~3);
   S.rk = (long long *)(S.rv + 64);
   S.ri = (int *)(S.rk + 64);
