@@ -185,11 +185,11 @@ def _pmc_entry(kernel, shape):
         d = json.load(open(os.path.join(ROOT, PMC_FILE)))
     except Exception:
         return None
-    k = d.get(kernel)
-    if not k:
-        return None
-    ks = k.get('shape', {})
-    return k if all(ks.get(n) == v for n, v in shape.items()) else None
+    # the record of the default workload, then those of other launch shapes (`more`: BASELINE configs 3 and 5, same script)
+    for k in [d.get(kernel)] + [m.get(kernel) for m in d.get('more', [])]:
+        if k and all(k.get('shape', {}).get(n) == v for n, v in shape.items()):
+            return k
+    return None
 
 
 def roofline(kernel, shape, bytes_per_env_step, envs, steps_per_launch, launch_us, extra=None):
