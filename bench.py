@@ -187,7 +187,7 @@ def _pmc_entry(kernel, shape):
         return None
     # the record of the default workload, then those of other launch shapes (`more`: BASELINE configs 3 and 5, same script)
     for k in [d.get(kernel)] + [m.get(kernel) for m in d.get('more', [])]:
-        if k and all(k.get('shape', {}).get(n) == v for n, v in shape.items()):
+        if k and all(k.get('shape', {}).get(n, False if n == 'persistent' else None) == v for n, v in shape.items()):
             return k
     return None
 
