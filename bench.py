@@ -2,6 +2,7 @@
 """bench.py — env-steps/s of the batched Drone2D environment on MI355X (BASELINE.json metric).
 
   python bench.py --gpus 1 --steps 600 --warmup 300
+  python bench.py --gpus N --steps K --warmup W          (no launcher: bench.py starts its own N ranks, one per GPU)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W
 
@@ -259,12 +260,12 @@ def stage_leg(torch, clock, env, params, rank, B, stages, K=500, Wm=100):
     return min(reps), reps
 
 
-def large_batch_legs(torch, clock, pkg, vec_env, params, worlds, rank, BL, chunk):
+def large_batch_legs(torch, clock, pkg, vec_env, params, worlds, rank, BL, chunk, workload):
     """The same three kernels on a batch far above the chip's wave slots (the workload's worlds tiled over it): the closed
     loop, the fused step and the raycast stage -- measured after the headline, never part of `value`."""
     nw = len(worlds)
     tiled = [worlds[i % nw] for i in range(BL)]
-    shape = {'workload': 'config2', 'envs': BL}
+    shape = {'workload': workload, 'envs': BL}
     out = {'envs': BL, 'distinct_worlds': nw}
     env = vec_env.VecDrone2DEnv(params, BL, device=clock.device, planner='Primitive', worlds=tiled, device_plugins=True, gaze='Oxford')
     env.closed_loop(300, auto_reset=True)
@@ -283,6 +284,44 @@ def large_batch_legs(torch, clock, pkg, vec_env, params, worlds, rank, BL, chunk
     us, reps = stage_leg(torch, clock, env, params, rank, BL, 'step', K=200, Wm=40)
     out['step_kernel'] = {'env_steps_per_s': BL / (us * 1e-6), 'repetitions_us': reps, 'roofline': roofline('k_stages', shape, algo, BL, 1, us)}
     return out
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N fresh child processes of this script, one rank per GPU
+    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment, exactly what torch.distributed.run would set), relay
+    rank 0's JSON line, and fail if any rank fails or the line does not report N ranks.  The parent never initialises the
+    GPU and never replaces a running program: the ranks are ordinary children (subprocess)."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    entry = os.environ.get('D2D_BENCH_ENTRY', os.path.abspath(__file__))   # tests substitute their CPU dry-run harness
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+        procs.append(subprocess.Popen([sys.executable, entry] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, _ = procs[0].communicate()
+    codes = [p.wait() for p in procs]
+    if any(codes):
+        sys.stdout.write(out0)
+        print(f'bench.py: rank exit codes {codes}', file=sys.stderr)
+        return 1
+    lines = [ln for ln in out0.splitlines() if ln.startswith('{')]
+    if len(lines) != 1:
+        sys.stdout.write(out0)
+        print('bench.py: rank 0 printed no JSON line', file=sys.stderr)
+        return 1
+    j = json.loads(lines[0])
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    if j.get('n_gpus') != n or j.get('n_ranks_seen', n) != n:   # (a --leg step / raycast line carries no collective)
+        print(f'bench.py: asked for {n} ranks, the line reports n_gpus={j.get("n_gpus")} n_ranks_seen={j.get("n_ranks_seen")}', file=sys.stderr)
+        return 1
+    return 0
 
 
 def main():
@@ -312,6 +351,15 @@ def main():
     ap.add_argument('--distinct-worlds', type=int, default=0,
                     help='build only this many seeded worlds per rank and tile them over the batch (0 = one world per env)')
     args = ap.parse_args()
+
+    if args.gpus < 1:
+        ap.error('--gpus must be >= 1')
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: this process only starts the N ranks (nothing here has touched the GPU)
+        sys.exit(launch_ranks(args.gpus))
+    if int(os.environ.get('WORLD_SIZE', '1')) != args.gpus:
+        sys.exit(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={os.environ.get("WORLD_SIZE")}: the line would misreport n_gpus; '
+                 'launch with --nproc-per-node equal to --gpus (or without a launcher: bench.py starts its own ranks)')
 
     import torch
     import drone2d_amd as pkg
@@ -378,6 +426,9 @@ def main():
                 cursor[0] += m
                 done += m
 
+    # BASELINE.json's metric names config 2 (10 agents, map_id = 1 + env); the other workloads say what they are
+    metric = ('env-steps/sec (batched) at 10 agents, map_id=1' if args.workload == 'config2' else
+              f'env-steps/sec (batched) at {env.N} agents, {args.workload}, map_id=1+env')
     line = None
     if args.leg in ('all', 'closed'):
         run(args.prologue)
@@ -437,7 +488,7 @@ def main():
                              'launch_mode': 'd2d_rollout: one k_stages launch per step'})
                 kern, kname, note = 'k_stages', 'k_stages (fused Drone2DEnv2.step)', 'one launch = one step of every env'
             line = {
-                'metric': 'env-steps/sec (batched) at 10 agents, map_id=1', 'value': value, 'unit': 'env-steps/s',
+                'metric': metric, 'value': value, 'unit': 'env-steps/s',
                 'n_gpus': world, 'steps': K, 'warmup': Wm, 'ms_per_step': elapsed * 1e3 / K,
                 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
                 'config': cfgd,
@@ -448,7 +499,7 @@ def main():
                                   'mean_cells_discovered': float(stats[:, 6].double().mean())},
             }
     elif rank == 0:
-        line = {'metric': 'env-steps/sec (batched) at 10 agents, map_id=1', 'value': None, 'unit': 'env-steps/s',
+        line = {'metric': metric, 'value': None, 'unit': 'env-steps/s',
                 'n_gpus': world, 'leg': args.leg, 'config': {'workload': descr.format(B=B), 'name': args.workload}}
 
     if rank == 0:
@@ -476,7 +527,7 @@ def main():
                 'roofline': roofline('raycast_stage', sshape, rb, B, 1, us,
                                      {'note': 'bytes: 36 N agents + N hit mask + R S ground-truth reads + R (S - 1) drone-map writes + 44 B pose'})}
         if args.large and world == 1 and args.leg == 'all' and closed and use_cuda:
-            line['large_batch'] = large_batch_legs(torch, clock, pkg, vec_env, params, worlds, rank, args.large, args.chunk)
+            line['large_batch'] = large_batch_legs(torch, clock, pkg, vec_env, params, worlds, rank, args.large, args.chunk, args.workload)
         if not args.no_cpu_baseline and world == 1 and args.leg == 'all':
             line['cpu_baseline'] = cpu_baseline(pkg, params, closed)
         print(json.dumps(line), flush=True)

@@ -16,5 +16,6 @@ from drone2d_amd import _lib  # noqa: E402
 from oracle_lib import OracleBackend  # noqa: E402
 
 _lib.HipBackend = lambda device='cpu': OracleBackend()
+os.environ['D2D_BENCH_ENTRY'] = os.path.abspath(__file__)   # ranks that bench.py starts itself (--gpus N, no launcher) come back here
 sys.argv = [os.path.join(ROOT, 'bench.py')] + sys.argv[1:]
 runpy.run_path(os.path.join(ROOT, 'bench.py'), run_name='__main__')

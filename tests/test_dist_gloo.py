@@ -154,3 +154,31 @@ def test_bench_two_rank_dry_run():
     r = j['roofline']
     assert r['bound'] == 'hbm' and r['unit'] == 'GB/s' and r['peak'] == 8000.0 and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-12
     assert r['algo_bytes_per_env_step'] == 3844.0          # SURVEY 8(d) for config 2, from the run's own N / R / L / cells per agent
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` WITHOUT torch.distributed.run (the way the driver calls N = 1): bench.py starts the two ranks
+    itself, relays rank 0's line and checks n_gpus == n_ranks_seen == 2.  (CPU dry run through tests/bench_dry_rank.py.)"""
+    import json
+    import subprocess
+    cmd = [sys.executable, os.path.join(ROOT, 'tests', 'bench_dry_rank.py'), '--gpus', '2', '--steps', '4', '--warmup', '2',
+           '--prologue', '2', '--envs', '4', '--workers', '0', '--dist-backend', 'gloo', '--single-device', '--leg', 'closed',
+           '--no-cpu-baseline']
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    env['OMP_NUM_THREADS'] = '1'
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, out.stdout
+    j = json.loads(lines[0])
+    assert j['n_gpus'] == 2 and j['n_ranks_seen'] == 2 and j['episode_stats']['envs'] == 8 and j['value'] > 0
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    """--gpus 2 under a launcher that started ONE rank would print a 1-rank number labelled n_gpus 2: refused."""
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE='1', RANK='0', LOCAL_RANK='0', OMP_NUM_THREADS='1')
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'bench_dry_rank.py'), '--gpus', '2', '--steps', '2',
+                          '--warmup', '1', '--envs', '2', '--workers', '0', '--leg', 'closed', '--no-cpu-baseline'],
+                         capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert out.returncode != 0 and 'WORLD_SIZE' in out.stderr
