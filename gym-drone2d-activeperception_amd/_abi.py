@@ -2,7 +2,7 @@
 the header exactly; tests/test_abi.py cross-checks sizes and constants against the header text."""
 import ctypes as C
 
-D2D_ABI_VERSION = 6
+D2D_ABI_VERSION = 7
 
 UNEXPLORED, OCCUPIED, UNOCCUPIED, DYNAMIC = 0, 1, 2, 3
 SM_WAIT_FOR_GOAL, SM_GOAL_REACHED, SM_PLANNING, SM_EXECUTING = 0, 1, 2, 3
@@ -31,7 +31,7 @@ DONE_CONTINUE, DONE_RESET, DONE_FREEZE = 0, 1, 2
 class Cfg(C.Structure):
     _fields_ = [(n, C.c_int32) for n in
                 ('abi_version', 'B', 'N', 'W', 'H', 'R', 'L', 'T', 'planner_mode', 'kf_enabled',
-                 'noise_rows', 'reserved1')] + \
+                 'noise_rows', 'noise_row0')] + \
                [(n, C.c_double) for n in
                 ('dt', 'scale', 'W_px', 'H_px', 'ray_off0', 'ray_dth', 'depth', 'drone_radius', 'yaw_rate',
                  'max_acc', 'max_steps', 'sigma', 'kf_lo_x', 'kf_hi_x', 'kf_lo_y', 'kf_hi_y')]

@@ -1784,7 +1784,7 @@ __device__ __attribute__((noinline)) void ph_gaze_stages(const ClosedArgs *ap, i
   EnvRegs r;
   load_regs(a->s, e, r);
   // this step's row of the measurement noise (d2d_cfg.noise_rows; utils.py:605 draws fresh normals every step)
-  const size_t noise_off = c.noise_rows > 1 ? (size_t)(tstep % c.noise_rows) * c.B * c.N * 2 : 0;
+  const size_t noise_off = c.noise_rows > 1 ? (size_t)((c.noise_row0 + tstep) % c.noise_rows) * c.B * c.N * 2 : 0;
   run_env<spec_full(SPEC), spec_wide(SPEC), spec_cone(SPEC)>(c, a->s, e, lane, STAGES, g, L, a->s.action[e], r, noise_off);
   if (lane == 0) store_regs(a->s, e, r);
   wave_sync_global();
@@ -1920,6 +1920,7 @@ int check(const d2d_cfg *c, const d2d_state *s) {
   if (c->abi_version != D2D_ABI_VERSION) return fail(-2, "ABI version mismatch");
   if (c->B < 0 || c->N < 0 || c->W <= 0 || c->H <= 0 || c->R <= 0 || c->L <= 0 || (c->L & 1) == 0 || c->T <= 0)
     return fail(-1, "bad dimensions");
+  if (c->noise_row0 < 0 || c->noise_row0 >= (c->noise_rows > 1 ? c->noise_rows : 1)) return fail(-1, "noise_row0 outside [0, noise_rows)");
   if (c->W > 32767 || c->H > 32767) return fail(-4, "grids of more than 32767 cells a side are not supported (16-bit cell planes in LDS)");
   if (!(c->scale >= 2.0) || c->scale != (double)(long long)c->scale)
     return fail(-4, "map_scale must be an integer >= 2 (scale 1 never advances a ray, utils.py:621)");
@@ -2098,7 +2099,7 @@ int d2d_rollout(const d2d_cfg *c, const d2d_state *s, int32_t nsteps, const doub
   for (int32_t t = 0; t < nsteps; ++t) {
     st.action = (const double D2D_AS *)(actions + (size_t)t * c->B);
     if (wp_steps) st.wp = (const double D2D_AS *)(wp_steps + (size_t)t * c->B * 6);
-    if (s->noise && c->noise_rows > 1) st.noise = s->noise + (size_t)(t % c->noise_rows) * c->B * c->N * 2;
+    if (s->noise && c->noise_rows > 1) st.noise = s->noise + (size_t)((c->noise_row0 + t) % c->noise_rows) * c->B * c->N * 2;
     rc = launch_stages(c, &st, D2D_ST_ALL, stream, pin, coll_out ? coll_out + (size_t)t * c->B : nullptr);
     if (rc) return rc;
   }
@@ -2176,7 +2177,7 @@ int d2d_closed_loop(const d2d_cfg *c, const d2d_state *s, const d2d_plan *p, int
   for (int32_t t = 0; t < nsteps; ++t) {
     if ((rc = gaze_launch(c, s, p, auto_reset ? init : nullptr, skip != 0, stream))) return rc;
     d2d_state sn = *s;  // this step's row of the measurement noise
-    if (s->noise && c->noise_rows > 1) sn.noise = s->noise + (size_t)(t % c->noise_rows) * c->B * c->N * 2;
+    if (s->noise && c->noise_rows > 1) sn.noise = s->noise + (size_t)((c->noise_row0 + t) % c->noise_rows) * c->B * c->N * 2;
     if (split) {
       if ((rc = launch_stages(c, &sn, D2D_ST_PERCEIVE | skip, stream))) return rc;
       if ((rc = plan_launch(c, s, p, skip != 0, stream))) return rc;

@@ -114,14 +114,20 @@ class VecDrone2DEnv:
     def set_noise(self, noise):
         """Standard-normal draws for the measurements (utils.py:605); required when var_cam != 0 (the reference takes them
         from np.random in agent order).  [B, N, 2]: the draws of the next step (every step of a multi-step call would reuse
-        them); [T, B, N, 2]: step t of the next rollout() / closed_loop() call draws from row t % T, as the reference draws
-        fresh normals every step."""
+        them); [T, B, N, 2]: a run of multi-step calls (rollout() / closed_loop()) draws row after row, step t of the run from
+        row t % T, as the reference draws fresh normals every step -- also when the run is cut into several calls
+        (d2d_cfg.noise_row0 is advanced by the steps of every call; set_noise() starts again at row 0)."""
         n = torch.as_tensor(noise, dtype=torch.float64)
         rows = n.shape[0] if n.dim() == 4 else 1
         n = n.reshape(rows, self.num_envs, self.cfg.N, 2).to(self.device).contiguous()
         self.state.noise = n
         self._st.noise = n.data_ptr()
         self.cfg.noise_rows = rows
+        self.cfg.noise_row0 = 0
+
+    def _advance_noise(self, nsteps):
+        if self.cfg.noise_rows > 1:
+            self.cfg.noise_row0 = (self.cfg.noise_row0 + int(nsteps)) % self.cfg.noise_rows
 
     def step(self, actions):
         """One fused Drone2DEnv2.step for every env.  Returns (obs, reward, done, info) of tensors."""
@@ -154,6 +160,7 @@ class VecDrone2DEnv:
         S = max(1, min(int(streams), self.num_envs))
         if S == 1 or self.device.type != 'cuda' or (self.state.noise is not None and self.cfg.noise_rows > 1):
             self.backend.rollout(self.cfg, self._st, T, actions, pin, coll)
+            self._advance_noise(T)
             return coll
         # sub-batch i owns envs [lo, hi): its own cfg (B = hi - lo) and state struct (every pointer offset by lo)
         import copy
@@ -217,6 +224,7 @@ class VecDrone2DEnv:
         mode = A.DONE_RESET if auto_reset else (A.DONE_FREEZE if freeze_done else A.DONE_CONTINUE)
         self.backend.closed_loop(self.cfg, self._st, self._plan, int(nsteps), mode,
                                  self._init_st if auto_reset else None)
+        self._advance_noise(nsteps)
         return self._result()
 
     def reset_plugins(self, mask=None):

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define D2D_ABI_VERSION 6
+#define D2D_ABI_VERSION 7
 
 /* grid cell codes, utils.py:11-16 */
 #define D2D_UNEXPLORED 0
@@ -133,9 +133,10 @@ typedef struct d2d_cfg {
   int32_t planner_mode;
   int32_t kf_enabled;  /* 1: Kalman trackers run on device (kf, kf_len must be set) */
   int32_t noise_rows;  /* rows of d2d_state.noise, each [B][N][2]: step t of a multi-step call (d2d_rollout, d2d_closed_loop)
-                          draws from row t % noise_rows -- the reference draws fresh normals every step (utils.py:605); 0 or 1 =
-                          one row used by every step (single-step entry points always use row 0) */
-  int32_t reserved1;
+                          draws from row (noise_row0 + t) % noise_rows -- the reference draws fresh normals every step
+                          (utils.py:605); 0 or 1 = one row used by every step (single-step entry points always use row 0) */
+  int32_t noise_row0;  /* the row the FIRST step of a multi-step call draws from (ABI 7): a caller that cuts a run into several
+                          calls advances it by the steps of each call, so that the pieces draw the rows the whole run would */
   double dt;           /* params.dt */
   double scale;        /* params.map_scale (x_scale == y_scale, utils.py:500-501) */
   double W_px, H_px;   /* params.map_size */

@@ -476,6 +476,7 @@ static int check(const d2d_cfg *c, const d2d_state *s) {
   if (c->abi_version != D2D_ABI_VERSION) return fail(-2, "ABI version mismatch");
   if (c->B < 0 || c->N < 0 || c->W <= 0 || c->H <= 0 || c->R <= 0 || c->L <= 0 || (c->L & 1) == 0)
     return fail(-1, "bad dimensions");
+  if (c->noise_row0 < 0 || c->noise_row0 >= (c->noise_rows > 1 ? c->noise_rows : 1)) return fail(-1, "noise_row0 outside [0, noise_rows)");
   if (!(c->scale >= 2)) return fail(-4, "map_scale < 2: the reference's ray march never advances (utils.py:621)");
   if (c->kf_enabled && (!s->kf || !s->kf_len)) return fail(-1, "kf_enabled without kf buffers");
   if (c->planner_mode == D2D_PLANNER_EXTERNAL && (!s->plan_ok || !s->wp_valid || !s->wp))
@@ -524,7 +525,7 @@ int d2d_oracle_rollout(const d2d_cfg *c, const d2d_state *s, int32_t nsteps, con
   for (int k = 0; k < nsteps; ++k) {
     t.action = actions + (size_t)k * c->B;
     if (wp_steps) t.wp = wp_steps + (size_t)k * c->B * 6;
-    if (s->noise && c->noise_rows > 1) t.noise = s->noise + (size_t)(k % c->noise_rows) * c->B * c->N * 2;
+    if (s->noise && c->noise_rows > 1) t.noise = s->noise + (size_t)((c->noise_row0 + k) % c->noise_rows) * c->B * c->N * 2;
     if (pin)
       for (int e = 0; e < c->B; ++e) {
         s->drone[(size_t)e * D2D_DF + D2D_D_X] = pin[2 * e];
@@ -1068,7 +1069,7 @@ int d2d_oracle_closed_loop(const d2d_cfg *c, const d2d_state *s, const d2d_plan 
     }
     if ((rc = d2d_oracle_gaze_stage(c, s, p, 0))) break;
     d2d_state sn = *s; /* this step's row of the measurement noise */
-    if (s->noise && c->noise_rows > 1) sn.noise = s->noise + (size_t)(t % c->noise_rows) * c->B * c->N * 2;
+    if (s->noise && c->noise_rows > 1) sn.noise = s->noise + (size_t)((c->noise_row0 + t) % c->noise_rows) * c->B * c->N * 2;
     if ((rc = d2d_oracle_run_stages(c, &sn, D2D_ST_PERCEIVE | skip, 0))) break;
     if ((rc = d2d_oracle_plan_stage(c, s, p, 0))) break;
     if ((rc = d2d_oracle_run_stages(c, s, D2D_ST_ACT | skip, 0))) break;

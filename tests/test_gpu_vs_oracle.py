@@ -251,7 +251,9 @@ def test_per_step_measurement_noise_rows(pkg, hip, oracle):
     n2 = rng.standard_normal((7, 4, d2.cfg.N, 2))
     for env in (d2, r2):
         env.set_noise(n2)
-        env.closed_loop(25, auto_reset=True)
+    r2.closed_loop(25, auto_reset=True)
+    for n in (10, 1, 14):                      # cut into several launches: the rows go on where the last call stopped (noise_row0)
+        d2.closed_loop(n, auto_reset=True)
     _assert_same(d2, r2, 'closed loop with noise rows')
 
 

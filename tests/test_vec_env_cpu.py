@@ -90,3 +90,28 @@ def test_zero_agents_and_parallel_world_build(pkg, oracle):
     b = vec_env.build_worlds(q, 70, workers=0)
     for x, y in zip(a, b):
         assert np.array_equal(x['agents'], y['agents']) and np.array_equal(x['gt'], y['gt'])
+
+
+def test_noise_rows_continue_across_chunked_calls(pkg, oracle):
+    """A run cut into several multi-step calls draws the noise rows the whole run would (d2d_cfg.noise_row0, ABI 7): before, every
+    call started again at row 0 and a chunked run replayed the same measurement noise with the period of the chunk."""
+    from drone2d_amd import vec_env
+    rng = np.random.RandomState(5)
+    p = pkg.Params(planner='Primitive', gaze_method='Rotating', agent_number=12, agent_radius=12, agent_max_speed=30, map_id=31,
+                   var_cam=2, init_pos=[250, 250], drone_max_speed=40)
+    whole = vec_env.VecDrone2DEnv(p, 3, backend=oracle, planner='Primitive', device_plugins=True, gaze='Rotating')
+    parts = vec_env.VecDrone2DEnv(p, 3, backend=oracle, planner='Primitive', device_plugins=True, gaze='Rotating')
+    noise = rng.standard_normal((7, 3, whole.cfg.N, 2))
+    whole.set_noise(noise)
+    parts.set_noise(noise)
+    whole.closed_loop(24, auto_reset=True)
+    for n in (5, 1, 9, 9):
+        parts.closed_loop(n, auto_reset=True)
+    assert parts.cfg.noise_row0 == 24 % 7
+    for name in ('kf', 'active', 'drone', 'dmap', 'counters'):
+        assert torch.equal(whole.state.t[name], parts.state.t[name]), name
+    assert int(whole.state.active.sum()) > 0
+    # a row index outside the table is refused
+    parts.cfg.noise_row0 = 7
+    with pytest.raises(Exception):
+        parts.closed_loop(1, auto_reset=True)
