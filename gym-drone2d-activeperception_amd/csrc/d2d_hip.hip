@@ -1578,14 +1578,20 @@ struct StagesKArgs {
   unsigned char *coll_out;
 };
 
+// The ONE parameter of the kernel is that block, by value: the kernarg segment then holds exactly a StagesKArgs at offset 0 by
+// construction (a separate parameter list would have to be kept in step with the struct by hand).
 template <int SPEC>
-__global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK, D2D_MIN_WAVES) void k_stages(d2d_cfg c_in, d2d_state s_in, uint32_t stages,
-                                                                                 const double *pin, unsigned char *coll_out) {
+__global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK, D2D_MIN_WAVES) void k_stages(StagesKArgs args) {
 #if defined(__HIP_DEVICE_COMPILE__)
   const StagesKArgs *ka = (const StagesKArgs *)(const __attribute__((address_space(4))) StagesKArgs *)__builtin_amdgcn_kernarg_segment_ptr();
 #else
   const StagesKArgs *ka = nullptr;  // the host pass only parses this
 #endif
+  const d2d_cfg &c_in = args.c;
+  const d2d_state &s_in = args.s;
+  const uint32_t stages = args.stages;
+  const double *pin = args.pin;
+  unsigned char *coll_out = args.coll_out;
   d2d_cfg c_folded;
   if (SPEC != 0) {
     c_folded = c_in;
@@ -1714,7 +1720,7 @@ __global__ void k_closed_args(ClosedArgs *dst, d2d_cfg c, d2d_state s, d2d_plan 
 template <int SPEC>
 __host__ __device__ inline int closed_wave_bytes(const d2d_cfg &c, const d2d_plan &p, int wpb) {
   int b = make_geom(c, wpb, spec_ncap(SPEC), spec_full(SPEC)).wave_bytes;
-  const int pb = plan_wave_bytes(c.N, p.nu, p.n_sample, c.W * c.H), gb = p.gaze == D2D_GAZE_OXFORD ? gaze_geom(c, p).wave_bytes : 0;
+  const int pb = plan_wave_bytes(c.N, p.nu, p.n_sample, c.W, c.H), gb = p.gaze == D2D_GAZE_OXFORD ? gaze_geom(c, p).wave_bytes : 0;
   b = b > pb ? b : pb;
   b = b > gb ? b : gb;
   return (b + 15) & ~15;
@@ -1944,27 +1950,32 @@ int launch_stages(const d2d_cfg *c, const d2d_state *s, uint32_t stages, void *s
   if (c->B == 0) return 0;
   d2d_state st = *s;
   if (!st.action) st.action = (const double D2D_AS *)st.drone;  // never dereferenced meaningfully without CONTROL
+  StagesKArgs ka;
+  memset(&ka, 0, sizeof ka);
+  ka.c = *c;
+  ka.s = st;
+  ka.stages = stages;
+  ka.pin = pin;
+  ka.coll_out = coll_out;
   if (spec_path(*c) && c->N > spec_ncap(2)) {
     const int wpb = pick_wpb(*c);
     const Geom g = make_geom(*c, wpb, 0, spec_full(3));
     const dim3 grid((c->B + wpb - 1) / wpb), block(WAVE * wpb);
     lds_optin(k_stages<3>, (size_t)g.wave_bytes * wpb);
-    hipLaunchKernelGGL(k_stages<3>, grid, block, (size_t)g.wave_bytes * wpb, (hipStream_t)stream, *c, st, stages, pin,
-                       coll_out);
+    hipLaunchKernelGGL(k_stages<3>, grid, block, (size_t)g.wave_bytes * wpb, (hipStream_t)stream, ka);
   } else if (spec_path(*c)) {
     const int spec = c->N <= spec_ncap(1) ? 1 : 2;
     const Geom g = make_geom(*c, WAVES_PER_BLOCK, spec_ncap(spec), spec_full(spec));
     const dim3 grid((c->B + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK), block(WAVE * WAVES_PER_BLOCK);
     const size_t lds = (size_t)g.wave_bytes * WAVES_PER_BLOCK;
-    if (spec == 1) hipLaunchKernelGGL(k_stages<1>, grid, block, lds, (hipStream_t)stream, *c, st, stages, pin, coll_out);
-    else hipLaunchKernelGGL(k_stages<2>, grid, block, lds, (hipStream_t)stream, *c, st, stages, pin, coll_out);
+    if (spec == 1) hipLaunchKernelGGL(k_stages<1>, grid, block, lds, (hipStream_t)stream, ka);
+    else hipLaunchKernelGGL(k_stages<2>, grid, block, lds, (hipStream_t)stream, ka);
   } else {
     const int wpb = pick_wpb(*c);
     const Geom g = make_geom(*c, wpb);
     const dim3 grid((c->B + wpb - 1) / wpb), block(WAVE * wpb);
     lds_optin(k_stages<0>, (size_t)g.wave_bytes * wpb);
-    hipLaunchKernelGGL(k_stages<0>, grid, block, (size_t)g.wave_bytes * wpb, (hipStream_t)stream, *c, st, stages, pin,
-                       coll_out);
+    hipLaunchKernelGGL(k_stages<0>, grid, block, (size_t)g.wave_bytes * wpb, (hipStream_t)stream, ka);
   }
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return fail(-3, hipGetErrorString(err));
@@ -2002,7 +2013,7 @@ int plan_check(const d2d_cfg *c, const d2d_state *s, const d2d_plan *p) {
     if (p->nu <= 0 || p->n_sample <= 0 || p->n_ts <= 0 || p->traj_cap < p->n_ts || p->node_cap < 2)
       return fail(-1, "plan: bad planner dimensions");
     if (!s->plan_ok || !s->wp_valid || !s->wp) return fail(-1, "plan: plan_ok / wp_valid / wp buffers missing");
-    if ((size_t)plan_wave_bytes(c->N, p->nu, p->n_sample, c->W * c->H) > LDS_HARD) return fail(-4, "plan: too many agents for the tracker staging in LDS");
+    if ((size_t)plan_wave_bytes(c->N, p->nu, p->n_sample, c->W, c->H) > LDS_HARD) return fail(-4, "plan: too many agents for the tracker staging in LDS");
   }
   if (p->gaze == D2D_GAZE_OXFORD) {
     if (!p->yaw_space || !p->tobs_tab || !p->pw_leaf || !p->pw_tree || !p->pw_rowleaf || !p->seen_step) return fail(-1, "plan: null gaze pointer");
@@ -2035,7 +2046,7 @@ int gaze_launch(const d2d_cfg *c, const d2d_state *s, const d2d_plan *p, const d
 
 int plan_launch(const d2d_cfg *c, const d2d_state *s, const d2d_plan *p, bool skip_done, void *stream) {
   if (p->planner != D2D_PLAN_PRIMITIVE || c->B == 0) return 0;
-  const size_t wb = (size_t)plan_wave_bytes(c->N, p->nu, p->n_sample, c->W * c->H);
+  const size_t wb = (size_t)plan_wave_bytes(c->N, p->nu, p->n_sample, c->W, c->H);
   int wpb = WAVES_PER_BLOCK;
   while (wpb > 1 && wb * wpb > LDS_SOFT) wpb >>= 1;
   const dim3 grid((c->B + wpb - 1) / wpb), block(WAVE * wpb);

@@ -190,34 +190,36 @@ __device__ __forceinline__ unsigned int key_hash(long long k) {
   return (unsigned int)(((unsigned long long)k * 0x9E3779B97F4A7C15ull) >> 32);
 }
 
-// Scratch layout of one env's search (private to this file): planes of node_cap entries each.
-struct NodePlanes {
-  double *px, *py, *vx, *vy, *cost, *total, *ax, *ay;
-  int2 *link;        // parent slot, itr
-  long long *key;
-  long long *state;  // 1 open, 2 closed
+// Scratch layout of one env's search (private to this file): ONE 96-byte record per node (D2D_NODE_F doubles, 16-byte aligned)
+//   +0 position(2)   +2 velocity(2)   +4 cost, key   +6 meta (int32 parent slot | int32 itr << 2 | state: 1 open, 2 closed), total_cost
+//   +8 acceleration(2)   +10 unused
+// so that a pop reads its node with four loads from one base pointer, a dict hit with two, and an insert writes five 16-byte
+// pieces (round 2 kept eleven planes: eleven base pointers -- scalar registers the loop did not have -- and one store per field).
+#define NR_POS 0
+#define NR_VEL 2
+#define NR_COST 4   // (cost, key)
+#define NR_META 6   // (meta, total_cost)
+#define NR_ACC 8
+struct NodeRecs {
+  double *b;
+  __device__ __forceinline__ double *rec(int i) const { return b + (size_t)i * D2D_NODE_F; }
 };
+__device__ __forceinline__ double2 ld2(const double *q) { return *(const double2 *)q; }
+__device__ __forceinline__ void st2(double *q, double a, double b) { *(double2 *)q = make_double2(a, b); }
+__device__ __forceinline__ double meta_pack(int parent, int itr, int state) { return __hiloint2double((itr << 2) | state, parent); }
+__device__ __forceinline__ int meta_parent(double m) { return __double2loint(m); }
+__device__ __forceinline__ int meta_itr(double m) { return __double2hiint(m) >> 2; }
+__device__ __forceinline__ int meta_state(double m) { return __double2hiint(m) & 3; }
 
-__device__ __forceinline__ NodePlanes node_planes(double *base, int cap) {
-  NodePlanes n;
-  n.px = base;
-  n.py = n.px + cap;
-  n.vx = n.py + cap;
-  n.vy = n.vx + cap;
-  n.cost = n.vy + cap;
-  n.total = n.cost + cap;
-  n.ax = n.total + cap;
-  n.ay = n.ax + cap;
-  n.link = (int2 *)(n.ay + cap);
-  n.key = (long long *)(n.ay + 2 * (size_t)cap);
-  n.state = n.key + cap;
-  return n;
-}
+// The dict of a search in LDS: open addressing over LH_N 16-bit entries, entry = 5 fingerprint bits of the key's hash << 11 |
+// slot + 1 (0 = empty).  A key that is not in the dict -- most successors -- is settled without leaving LDS; a fingerprint match
+// is confirmed against the node's key in its record (the same load brings its cost and state).  Holds LH_MAX keys / slots below
+// 2047; a search that outgrows it (large primitive sets) moves its dict to the hash table in global memory, once, and goes on there.
+#define LH_N 1024
+#define LH_MAX 896
 
-// LDS of one search (besides the trackers): small hand-off arrays so that the per-expansion chain has as few global
-// round trips and cross-lane shuffles as possible
 #ifdef D2D_SEARCH_PROF
-// Diagnostic build only (tools/search_prof.sh): shader-clock time of env 0's search per section of the expansion loop
+// Diagnostic build only (tools/search_prof.py): shader-clock time of env 0's search per section of the expansion loop
 __device__ unsigned long long d2d_search_prof[16];
 #define SP_T(var)                                              \
   do {                                                         \
@@ -242,23 +244,25 @@ __device__ unsigned long long d2d_search_prof[16];
 #endif
 
 struct SearchLds {
-  int *chain;       // [128] path slots; during the search [0..63] = lane of the r-th valid primitive, [64..127] = its free count
+  int *chain;       // [128] path slots; during the search: the 64-bucket table of the successors' keys (de-duplication)
   double *us;       // [nu] u_space
   double *st;       // [n_sample][2] t, t**2
   double *pc;       // [nu * nu] (x_acc**2 + y_acc**2) / 100 of every primitive (traj_planner.py:184): one division per search, not per expansion
-  double *rv;       // [64] reduction / de-duplication values (candidate costs)
-  long long *rk;    // [64] de-duplication keys
-  int *ri;          // [64] reduction indices
+  double *rv;       // [64] accelerations x of the primitives that pass the speed limit, by rank; de-duplication values (candidate costs)
+  long long *rk;    // [64] ... accelerations y; de-duplication keys; occupancy rows while the wall rows are built
+  int *ri;          // [64] de-duplication lanes
   int *misc;        // [4] misc[0] = number of active trackers staged by the quick part of the stage
   double *tot;      // [ntot] total_cost of the first nodes, +inf once closed (the min() scan reads these)
   int ntot;         // search_lds_nodes(N)
-  unsigned char *map;  // [W * H] copy of the explored map for the collision probes, or null when it does not fit
+  unsigned long long *prow;  // [64] wall rows: bit j of row i = "a collision sample in cell (i, j) touches a wall" (Planner.is_free's five
+                             // probes folded into one), or null when the grid has more than 64 cells a side
+  unsigned short *lh;        // [LH_N] the dict (see LH_N)
 };
 
 // nodes whose total_cost is mirrored in LDS: 512 (a capped search makes about 800); with more than 64 agents the six-plane
 // tracker staging grows and 256 keep the planner stage within three 4-wave workgroups per CU (BASELINE config 3: 13.4 KB per wave)
 __host__ __device__ inline int search_lds_nodes(int N) { return N > 64 ? 256 : 512; }
-#define D2D_SEARCH_LDS_MAP 4096
+__host__ __device__ inline bool search_wall_rows(int W, int H) { return W <= 64 && H <= 64; }
 
 // Primitive.plan's search (traj_planner.py:128-218) by one wave.  Returns the number of waypoints written, -1 = failure.
 // 0 is a success: the start node is the goal node (target within the search threshold of the start), the reference
@@ -266,7 +270,7 @@ __host__ __device__ inline int search_lds_nodes(int N) { return N > 64 ? 256 : 5
 __device__ int plan_search(const d2d_cfg &c, const d2d_state &s, const d2d_plan &p, int e, int lane, const TrkView &T,
                            const SearchLds &S, const unsigned char *__restrict__ dm, double inv_scale) {
   const double H = p.horizon;
-  const NodePlanes nd = node_planes(p.nodes + (size_t)e * p.node_cap * D2D_NODE_F, p.node_cap);
+  const NodeRecs nd = {p.nodes + (size_t)e * p.node_cap * D2D_NODE_F};
   int *__restrict__ tab = p.hash + (size_t)e * p.hash_cap;
   double *__restrict__ traj = p.traj + (size_t)e * p.traj_cap * 4;
   int *stat = p.plan_stat + (size_t)e * 4;
@@ -281,7 +285,6 @@ __device__ int plan_search(const d2d_cfg &c, const d2d_state &s, const d2d_plan 
   unsigned long long spacc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
   SP_T(spa);
-  for (int i = lane; i < p.hash_cap; i += WAVE) tab[i] = 0;
   for (int i = lane; i < p.nu; i += WAVE) S.us[i] = p.u_space[i];
   {
     const FastDiv fdu(p.nu);
@@ -293,53 +296,81 @@ __device__ int plan_search(const d2d_cfg &c, const d2d_state &s, const d2d_plan 
     }
   }
   for (int i = lane; i < 2 * p.n_sample; i += WAVE) S.st[i] = p.sample_t[i];
-  const bool lds_map = S.map != nullptr;
-  if (lds_map) {  // the whole explored map (2.5 KB at 50 x 50): every probe of the search comes from LDS
-    const int nb = c.W * c.H;
-    if ((nb & 3) == 0 && (((size_t)dm) & 3) == 0) {
-      const unsigned int *src = (const unsigned int *)dm;
-      unsigned int *dst = (unsigned int *)S.map;
-      for (int i = lane; i < nb / 4; i += WAVE) dst[i] = src[i];
-    } else {
-      for (int i = lane; i < nb; i += WAVE) S.map[i] = dm[i];
+  {
+    unsigned int *lh32 = (unsigned int *)S.lh;
+    for (int i = lane; i < LH_N / 2; i += WAVE) lh32[i] = 0u;
+  }
+  // integer probes for the collision samples: grid scale 10, map below 81920 px, integer safety distance (the samples are
+  // integer-valued: np.around)
+  const bool int_walls = c.scale == 10.0 && c.W_px <= 81919.0 && c.H_px <= 81919.0 && c.W_px == floor(c.W_px) &&
+                         c.H_px == floor(c.H_px) && c.W_px >= 1.0 && c.H_px >= 1.0 && p.safe_dist >= 0.0 &&
+                         p.safe_dist <= 1048576.0 && p.safe_dist == floor(p.safe_dist);
+  const int safe_i = int_walls ? (int)p.safe_dist : 0, wpx_i = int_walls ? (int)c.W_px : 1, hpx_i = int_walls ? (int)c.H_px : 1;
+  // The five probes of Planner.is_free (traj_planner.py:33-50: (x -+ d, y), (x, y), (x, y -+ d), out of the map = wall) for an
+  // integer sample, a safety distance of k whole cells and a map of whole cells: the probes are the cells (i -+ k, j), (i, j),
+  // (i, j -+ k) of the sample's cell (i, j), a probe leaves the map iff i < k, i >= W - k, j < k or j >= H - k.  Their OR is one bit
+  // of a row word built once per search from the explored map: row i = occ[i] | occ[i - k] | occ[i + k] | occ[i] << k | occ[i] >> k |
+  // border.  One LDS read per sample instead of five and a fifth of the arithmetic.
+  const int kcell = safe_i / 10;
+  const bool rows = S.prow != nullptr && int_walls && c.W <= 64 && c.H <= 64 && c.W_px == 10.0 * (double)c.W &&
+                    c.H_px == 10.0 * (double)c.H && safe_i == 10 * kcell && 2 * kcell <= min(c.W, c.H);
+  if (rows) {
+    int olo = 0, ohi = 0;  // lane i: the occupancy bits of grid row i (bit j = explored map holds OCCUPIED at (i, j))
+    const int jc = min(lane, c.H - 1);
+    for (int i0 = 0; i0 < c.W; i0 += 8) {
+      unsigned char v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = dm[min(i0 + u, c.W - 1) * c.H + jc];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (i0 + u < c.W) {  // wave-uniform
+          const unsigned long long m = __ballot(lane < c.H && v[u] == D2D_OCCUPIED);
+          olo = lane == i0 + u ? (int)(unsigned int)m : olo;
+          ohi = lane == i0 + u ? (int)(unsigned int)(m >> 32) : ohi;
+        }
+      }
     }
+    const unsigned long long occ = ((unsigned long long)(unsigned int)ohi << 32) | (unsigned int)olo;
+    unsigned long long *orow = (unsigned long long *)S.rk;
+    orow[lane] = occ;
+    wave_sync_lds();
+    const unsigned long long up = orow[max(lane - kcell, 0)], dn = orow[min(lane + kcell, WAVE - 1)];
+    const unsigned long long edge = kcell > 0 ? ((1ull << kcell) - 1ull) : 0ull;
+    const unsigned long long edge_hi = kcell > 0 ? (edge << (c.H - kcell)) : 0ull;
+    unsigned long long pr = occ | up | dn | (occ << kcell) | (occ >> kcell) | edge | edge_hi;
+    if (lane < kcell || lane >= c.W - kcell) pr = ~0ull;
+    wave_sync_lds();  // the occupancy rows have been read: rk is free again
+    S.prow[lane] = pr;
   }
   const double kInf = __longlong_as_double(0x7ff0000000000000ll);
   // norm(v_end) < vmax  <=>  v.v <= (largest s with sqrt(s) < vmax)  -- sq_threshold of the double below vmax;
   // norm(p - target) <= goal_tol  <=>  d.d <= sq_threshold(goal_tol): no square root per expansion
   const double vmax2 = p.vmax > 0.0 ? sq_threshold(__longlong_as_double(__double_as_longlong(p.vmax) - 1)) : -1.0;
   const double goal2 = sq_threshold(p.goal_tol);
-  wave_sync_global();
+  wave_sync_lds();
   if (lane == 0) {
     const double x = dr[D2D_D_X], y = dr[D2D_D_Y], vx = dr[D2D_D_VX], vy = dr[D2D_D_VY];
-    nd.px[0] = x; nd.py[0] = y; nd.vx[0] = vx; nd.vy[0] = vy;
-    nd.cost[0] = 0.0;
-    nd.total[0] = 0.0 + 0.5 * norm2(x - tx, y - ty) + 0.1 * norm2(vx, vy);  // traj_planner.py:88
-    nd.ax[0] = 0.0; nd.ay[0] = 0.0;
-    nd.link[0] = make_int2(-1, 0);
+    const double tot0 = 0.0 + 0.5 * norm2(x - tx, y - ty) + 0.1 * norm2(vx, vy);  // traj_planner.py:88
     const long long k = node_key(x, y, vx, vy);
-    nd.key[0] = k;
-    nd.state[0] = 1;
-    tab[key_hash(k) & hmask] = 1;
-    S.tot[0] = nd.total[0];
+    double *r0 = nd.rec(0);
+    st2(r0 + NR_POS, x, y);
+    st2(r0 + NR_VEL, vx, vy);
+    st2(r0 + NR_COST, 0.0, __longlong_as_double(k));
+    st2(r0 + NR_META, meta_pack(-1, 0, 1), tot0);
+    st2(r0 + NR_ACC, 0.0, 0.0);
+    const unsigned int h32 = key_hash(k);
+    S.lh[h32 >> 22] = (unsigned short)((((h32 >> 17) & 0x1fu) << 11) | 1u);
+    S.tot[0] = tot0;
   }
   wave_sync_global();
   SP_T(spb);
   SP_ADD(10, spa, spb);
   int nn = 1, open_n = 1, goal = -1, itr = 0, expansions = 0;
   bool overflow = false;
+  bool lds_dict = true;  // the dict lives in LDS (S.lh); false once the search has outgrown it: then in `tab`
   const int nprim = p.nu * p.nu;
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
   const FastDiv fd_nu(p.nu), fd_ns(p.n_sample);
-  // integer probes for the collision samples (plan_wall_int): grid scale 10, map below 81920 px, integer safety distance
-  const bool int_walls = c.scale == 10.0 && c.W_px <= 81919.0 && c.H_px <= 81919.0 && c.W_px == floor(c.W_px) &&
-                         c.H_px == floor(c.H_px) && c.W_px >= 1.0 && c.H_px >= 1.0 && p.safe_dist >= 0.0 &&
-                         p.safe_dist <= 1048576.0 && p.safe_dist == floor(p.safe_dist);
-  const int safe_i = int_walls ? (int)p.safe_dist : 0, wpx_i = int_walls ? (int)c.W_px : 1, hpx_i = int_walls ? (int)c.H_px : 1;
-  bool pend = false;  // a hash insert whose compare-and-swap result has not been looked at yet
-  unsigned int pend_h = 0;
-  int pend_old = 0, pend_val = 0;
-  (void)pend; (void)pend_h; (void)pend_old; (void)pend_val;
   for (;;) {
     itr += 1;
     if (open_n == 0 || itr >= p.max_itr) break;
@@ -354,7 +385,7 @@ __device__ int plan_search(const d2d_cfg &c, const d2d_state &s, const d2d_plan 
     bool fenced = false;
     {
       // the first S.ntot nodes from their LDS mirror (closed = +inf; an open node with an infinite or
-      // NaN cost is told apart by the state plane below, which such a search then falls back to)
+      // NaN cost is told apart by the state in its record below, which such a search then falls back to)
       const int nl = min(nn, S.ntot);
       for (int s0 = 0; s0 < nl; s0 += 4 * WAVE) {
         double t4[4];
@@ -368,30 +399,28 @@ __device__ int plan_search(const d2d_cfg &c, const d2d_state &s, const d2d_plan 
           bidx = take ? si : bidx;
         }
       }
-      // The stores of the previous expansion (node planes, hash table) are drained HERE, not at its end: the scan of the LDS
+      // The stores of the previous expansion (node records) are drained HERE, not at its end: the scan of the LDS
       // mirror above does not need them, so it runs while they are in flight.
       if (nn > nl) {
         wave_sync_global();
         fenced = true;
       }
-      for (int s0 = nl; s0 < nn; s0 += WAVE) {  // beyond the mirror: state and cost fetched together
+      for (int s0 = nl; s0 < nn; s0 += WAVE) {  // beyond the mirror: state and cost come together
         const int si = s0 + lane;
-        const int sc = min(si, nn - 1);
-        const long long stt = nd.state[sc];
-        const double t = nd.total[sc];
-        const bool take = (si < nn) & (stt == 1) & (t < best);
-        best = take ? t : best;
+        const double2 mt = ld2(nd.rec(min(si, nn - 1)) + NR_META);
+        const bool take = (si < nn) & (meta_state(mt.x) == 1) & (mt.y < best);
+        best = take ? mt.y : best;
         bidx = take ? si : bidx;
       }
     }
     bidx = wave_argmin(best, bidx);  // first minimal entry in slot order
-    if (!fenced) wave_sync_global();  // before the state plane, the popped node's fields and the dict probes are read
+    if (!fenced) wave_sync_global();  // before the popped node's record and the records behind dict hits are read
     if (__builtin_amdgcn_readfirstlane(bidx) == 0x7fffffff) {
-      // every open node has a non-finite cost (wild inputs): the literal scan over the state plane decides
+      // every open node has a non-finite cost (wild inputs): the literal scan over the states decides
       int fb = 0x7fffffff;
       for (int s0 = 0; s0 < nn; s0 += WAVE) {
         const int si = s0 + lane;
-        if (si < nn && nd.state[si] == 1 && fb == 0x7fffffff) fb = si;
+        if (si < nn && fb == 0x7fffffff && meta_state(nd.rec(si)[NR_META]) == 1) fb = si;
       }
       for (int o = 32; o > 0; o >>= 1) fb = min(fb, __shfl_xor(fb, o, WAVE));
       bidx = fb;
@@ -399,8 +428,11 @@ __device__ int plan_search(const d2d_cfg &c, const d2d_state &s, const d2d_plan 
     const int cur = __builtin_amdgcn_readfirstlane(bidx);
     SP_T(sp1);
     SP_ADD(0, sp0, sp1);
-    const double px = nd.px[cur], py = nd.py[cur], vx = nd.vx[cur], vy = nd.vy[cur], ccost = nd.cost[cur];
-    const int citr = nd.link[cur].y;
+    const double *rc = nd.rec(cur);
+    const double2 cpos = ld2(rc + NR_POS), cvel = ld2(rc + NR_VEL);
+    const double ccost = rc[NR_COST];
+    const int citr = meta_itr(rc[NR_META]);
+    const double px = cpos.x, py = cpos.y, vx = cvel.x, vy = cvel.y;
     SP_T(sp2);
     SP_ADD(1, sp1, sp2);
     if (__builtin_fma(py - ty, py - ty, (px - tx) * (px - tx)) <= goal2) {  // :158
@@ -408,7 +440,7 @@ __device__ int plan_search(const d2d_cfg &c, const d2d_state &s, const d2d_plan 
       break;
     }
     if (lane == 0) {
-      nd.state[cur] = 2;
+      ((int *)(nd.rec(cur) + NR_META))[1] = (citr << 2) | 2;
       if (cur < S.ntot) S.tot[cur] = kInf;
     }
     open_n -= 1;
@@ -430,40 +462,22 @@ __device__ int plan_search(const d2d_cfg &c, const d2d_state &s, const d2d_plan 
       const int myrank = __popcll(vm & lt_mask);
       SP_T(sp3);
       SP_ADD(2, sp2, sp3);
-#ifndef D2D_SEARCH_PLAIN
-      // inserts of the previous batch / expansion whose compare-and-swap lost its bucket to another lane (rare) go on from the
-      // next bucket: the swaps were issued without waiting for their result (below); every probe comes after this point
-      if (__any(pend)) {
-        if (pend && pend_old != 0) {
-          unsigned int hh = (pend_h + 1u) & hmask;
-          for (int guard = 0; guard < p.hash_cap; ++guard) {
-            if (atomicCAS(&tab[hh], 0, pend_val) == 0) break;
-            hh = (hh + 1) & hmask;
-          }
-        }
-        pend = false;
-      }
-      // the successor's dict key does not depend on the collision test: its first bucket is fetched now and arrives while the
-      // samples are tested (LDS only).  End point and key are evaluated again afterwards: two registers live across the samples.
-      unsigned int h0;
-      int sv0;
       {
-        const double ex0 = rint((px + H * vx) + (H * H) * hx), ey0 = rint((py + H * vy) + (H * H) * hy);
-        h0 = key_hash(node_key(ex0, ey0, vex, vey)) & hmask;
-        sv0 = __hip_atomic_load(&tab[ok ? h0 : 0u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-#endif
-      {
-        int *plist = chain, *pcnt = chain + WAVE;  // the path buffer is free during the search
+        // the accelerations of the primitives that passed, by rank: the pairs fetch theirs with one LDS read
         const int nv = __popcll(vm);
-        if (ok) plist[myrank] = pi;
-        pcnt[lane] = 0;
+        double *rax = S.rv, *ray = (double *)S.rk;
+        if (ok) {
+          rax[myrank] = hx;
+          ray[myrank] = hy;
+        }
         wave_sync_lds();
         const int npair = nv * p.n_sample;
-        // two rounds of pairs in flight (about ten primitives x eight samples = 80 pairs): each round is a chain of
-        // dependent LDS round trips (list -> tables -> map bytes -> counter), clamped indices keep both chains unconditional
+        const int my_lo = myrank * p.n_sample;  // this primitive's pairs: [my_lo, my_lo + n_sample)
+        int nfree = 0;
+        // two rounds of pairs in flight (about ten primitives x eight samples = 80 pairs); which samples are free comes back as
+        // ballots: every primitive counts the set bits of its own pairs -- no LDS counters, no hand-off
         for (int q0 = 0; q0 < npair; q0 += 2 * WAVE) {
-          int pr[2], sia[2], sja[2], si[2];
+          int pr[2], si[2];
           bool in[2], fr[2], fits[2];
           double sxv[2], syv[2], tgv[2];
 #pragma unroll
@@ -472,102 +486,111 @@ __device__ int plan_search(const d2d_cfg &c, const d2d_state &s, const d2d_plan 
             in[u] = q < npair;
             fd_ns.divmod(in[u] ? q : 0, pr[u], si[u]);
           }
-          int pl[2];
-#pragma unroll
-          for (int u = 0; u < 2; ++u) pl[u] = plist[pr[u]];
-#pragma unroll
-          for (int u = 0; u < 2; ++u) fd_nu.divmod(pl[u], sia[u], sja[u]);
-          double ux[2], uy[2], tt[2], tt2[2];
+          double shx[2], shy[2], tt[2], tt2[2];
 #pragma unroll
           for (int u = 0; u < 2; ++u) {
-            ux[u] = S.us[sia[u]]; uy[u] = S.us[sja[u]]; tt[u] = S.st[2 * si[u]]; tt2[u] = S.st[2 * si[u] + 1];
+            shx[u] = rax[pr[u]]; shy[u] = ray[pr[u]]; tt[u] = S.st[2 * si[u]]; tt2[u] = S.st[2 * si[u] + 1];
           }
 #pragma unroll
           for (int u = 0; u < 2; ++u) {
-            const double shx = ux[u] / 2, shy = uy[u] / 2;
-            const double sx = rint(__builtin_fma(tt2[u], shx, px + tt[u] * vx)), sy = rint(__builtin_fma(tt2[u], shy, py + tt[u] * vy));
+            const double sx = rint(__builtin_fma(tt2[u], shx[u], px + tt[u] * vx)), sy = rint(__builtin_fma(tt2[u], shy[u], py + tt[u] * vy));
             const double tg = tt[u] + (double)citr * H;
             sxv[u] = sx; syv[u] = sy; tgv[u] = tg;
             fits[u] = fabs(sx) <= 4194304.0 && fabs(sy) <= 4194304.0;  // also false for NaN
           }
-          if (int_walls && __all((int)fits[0] & (int)fits[1])) {  // wave-uniform: integer probes, see plan_wall_int
+          if (int_walls && __all((int)fits[0] & (int)fits[1])) {  // wave-uniform: integer probes
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
               const int xi = (int)sxv[u], yi = (int)syv[u];
-              const bool wall = lds_map ? plan_wall_int(c, (const unsigned char *)S.map, xi, yi, safe_i, wpx_i, hpx_i)
-                                        : plan_wall_int(c, dm, xi, yi, safe_i, wpx_i, hpx_i);
+              bool wall;
+              if (rows) {
+                const bool inside = ((unsigned int)xi < (unsigned int)wpx_i) & ((unsigned int)yi < (unsigned int)hpx_i);
+                const int ci = (int)(__umul24((unsigned int)min(max(xi, 0), wpx_i - 1), 52429u) >> 19);
+                const int cj = (int)(__umul24((unsigned int)min(max(yi, 0), hpx_i - 1), 52429u) >> 19);
+                wall = !inside | (((S.prow[ci] >> cj) & 1ull) != 0ull);
+              } else {
+                wall = plan_wall_int(c, dm, xi, yi, safe_i, wpx_i, hpx_i);
+              }
               fr[u] = !wall && !plan_hits_tracker(T, sxv[u], syv[u], tgv[u]);
             }
           } else {
 #pragma unroll
-            for (int u = 0; u < 2; ++u)
-              fr[u] = lds_map ? plan_is_free(c, p, (const unsigned char *)S.map, T, sxv[u], syv[u], tgv[u], inv_scale)
-                              : plan_is_free(c, p, dm, T, sxv[u], syv[u], tgv[u], inv_scale);
+            for (int u = 0; u < 2; ++u) fr[u] = plan_is_free(c, p, dm, T, sxv[u], syv[u], tgv[u], inv_scale);
           }
 #pragma unroll
-          for (int u = 0; u < 2; ++u)
-            if (in[u] & fr[u]) atomicAdd(&pcnt[pr[u]], 1);
+          for (int u = 0; u < 2; ++u) {
+            const unsigned long long fm = __ballot(in[u] & fr[u]);
+            const int qb = q0 + u * WAVE;  // this round holds the pairs [qb, qb + 64)
+            const int lo = max(my_lo, qb) - qb, hi = min(my_lo + p.n_sample, qb + WAVE) - qb;
+            if (hi > lo) {
+              const unsigned long long w = fm >> lo;
+              nfree += __popcll(hi - lo >= WAVE ? w : (w & ((1ull << (hi - lo)) - 1ull)));
+            }
+          }
         }
-        wave_sync_lds();
-        if (ok) ok = pcnt[myrank] == p.n_sample;
-        wave_sync_lds();
+        if (ok) ok = nfree == p.n_sample;
       }
       SP_T(sp4);
       SP_ADD(3, sp3, sp4);
       const double ex = rint((px + H * vx) + (H * H) * hx), ey = rint((py + H * vy) + (H * H) * hy);  // :182
       const double cost = ccost + S.pc[ok ? pi : 0] + 10;                                             // :184, the term from its table
       const long long key = node_key(ex, ey, vex, vey);
+      const unsigned int h32 = key_hash(key);
       // ---- :192-202 for all successors of the batch at once ----
       int slot = -1;
-      long long slot_state = 0;  // state and cost of the node found, fetched in the same round trip as its key
+      int slot_state = 0;  // state and cost of the node found, fetched in the same round trip as its key
       double slot_cost = 0.0;
-#ifdef D2D_SEARCH_PLAIN
-      unsigned int h = key_hash(key) & hmask;
-      if (ok) {
-        for (int guard = 0; guard < p.hash_cap; ++guard) {
-          const int sv = __hip_atomic_load(&tab[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // written by atomics
-          if (sv == 0) break;
-          const long long k2 = nd.key[sv - 1], st2 = nd.state[sv - 1];
-          const double c2 = nd.cost[sv - 1];
-          if (k2 == key) {
-            slot = sv - 1;
-            slot_state = st2;
-            slot_cost = c2;
-            break;
+      unsigned int h = 0;  // ends at the bucket with the key, or at the empty bucket a new key goes into
+      if (lds_dict) {
+        h = h32 >> 22;
+        const unsigned int fp = (h32 >> 17) & 0x1fu;
+        if (ok) {
+          for (int guard = 0; guard < LH_N; ++guard) {
+            const unsigned int ent = S.lh[h];
+            if (ent == 0u) break;
+            if ((ent >> 11) == fp) {
+              const int sl = (int)(ent & 0x7ffu) - 1;
+              const double *r2 = nd.rec(sl);
+              const double2 ck = ld2(r2 + NR_COST);
+              const double m2 = r2[NR_META];
+              if (__double_as_longlong(ck.y) == key) {
+                slot = sl;
+                slot_state = meta_state(m2);
+                slot_cost = ck.x;
+                break;
+              }
+            }
+            h = (h + 1u) & (LH_N - 1u);
           }
-          h = (h + 1) & hmask;
+        }
+      } else {
+        h = h32 & hmask;
+        if (ok) {
+          for (int guard = 0; guard < p.hash_cap; ++guard) {
+            const int sv = __hip_atomic_load(&tab[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // written by atomics
+            if (sv == 0) break;
+            const double *r2 = nd.rec(sv - 1);
+            const double2 ck = ld2(r2 + NR_COST);
+            const double m2 = r2[NR_META];
+            if (__double_as_longlong(ck.y) == key) {
+              slot = sv - 1;
+              slot_state = meta_state(m2);
+              slot_cost = ck.x;
+              break;
+            }
+            h = (h + 1) & hmask;
+          }
         }
       }
-#else
-      unsigned int h = h0;  // ends at the bucket with the key, or at the empty bucket a new key goes into
-      if (ok) {
-        int sv = sv0;
-        for (int guard = 0; guard < p.hash_cap; ++guard) {
-          if (sv == 0) break;
-          const long long k2 = nd.key[sv - 1], st2 = nd.state[sv - 1];
-          const double c2 = nd.cost[sv - 1];
-          if (k2 == key) {
-            slot = sv - 1;
-            slot_state = st2;
-            slot_cost = c2;
-            break;
-          }
-          h = (h + 1) & hmask;
-          sv = __hip_atomic_load(&tab[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // written by atomics
-        }
-      }
-#endif
       SP_T(sp5);
       SP_ADD(4, sp4, sp5);
       // the successors among themselves (rank order = lane order = generation order): the first lane of a key owns its
-      // place in the dict, the cheapest (earliest on ties) its value.  Repeats within one expansion are rare, so the
-      // common path only ASKS whether any two of the ~10 keys are equal -- one scalar round per successor (readlane of
-      // its key, compare, ballot), no LDS hand-off; the full resolution through LDS runs when the answer is yes.
-      const unsigned long long m = __ballot(ok);
-      const int nok = __popcll(m), rank = __popcll(m & lt_mask);
+      // place in the dict, the cheapest (earliest on ties) its value.  Repeats within one expansion are rare:
       // every successor puts its key into a 64-bucket LDS table (the path buffer, free at this point) by compare-and-swap:
       // finding its own key there = a repeat; another key = next bucket.  One or two LDS round trips for ten keys, and exact:
       // the resolution below runs only when two successors really share a key (or a key equals the empty marker, 0)
+      const unsigned long long m = __ballot(ok);
+      const int nok = __popcll(m), rank = __popcll(m & lt_mask);
       unsigned long long dupm = 0;
       {
         unsigned long long *bk = (unsigned long long *)chain;
@@ -589,6 +612,7 @@ __device__ int plan_search(const d2d_cfg &c, const d2d_state &s, const d2d_plan 
       int leader = lane, wlane = lane;
       double wcost = cost;
       if (dupm != 0ull) {  // rare: a plain loop keeps the register pressure of the common path low
+        wave_sync_lds();   // (the accelerations by rank in rv / rk have been consumed)
         if (ok) {
           S.rk[rank] = key;
           S.rv[rank] = cost;
@@ -627,38 +651,65 @@ __device__ int plan_search(const d2d_cfg &c, const d2d_state &s, const d2d_plan 
       const int gslot = __shfl(myslot, leader, WAVE);  // the slot of my group
       const bool write = ok && wlane == lane && (!exists || (!closed && ecost > wcost));
       if (write) {
-        nd.px[gslot] = ex; nd.py[gslot] = ey; nd.vx[gslot] = vex; nd.vy[gslot] = vey;
-        nd.cost[gslot] = cost;
+        double *rw = nd.rec(gslot);
         const double tot = cost + 0.5 * norm2(ex - tx, ey - ty) + 0.1 * norm2(vex, vey);
-        nd.total[gslot] = tot;
+        st2(rw + NR_POS, ex, ey);
+        st2(rw + NR_VEL, vex, vey);
+        st2(rw + NR_COST, cost, __longlong_as_double(key));
+        st2(rw + NR_META, meta_pack(cur, citr + 1, 1), tot);
+        st2(rw + NR_ACC, ax, ay);
         if (gslot < S.ntot) S.tot[gslot] = tot;
-        nd.ax[gslot] = ax; nd.ay[gslot] = ay;
-        nd.link[gslot] = make_int2(cur, citr + 1);
-        nd.key[gslot] = key;
-        nd.state[gslot] = 1;
+      }
+      // ---- the new keys into the dict ----
+      if (lds_dict && (nn + nnew > LH_MAX)) {
+        // The search has outgrown the LDS dict (large primitive sets): every node so far goes into the hash table in global
+        // memory, once, and the dict lives there from here on.  (The new nodes of this batch follow below like all later ones.)
+        for (int i = lane; i < p.hash_cap; i += WAVE) tab[i] = 0;
+        wave_sync_global();
+        for (int s0 = 0; s0 < nn; s0 += WAVE) {
+          const int si = s0 + lane;
+          if (si < nn) {
+            const long long k2 = __double_as_longlong(nd.rec(si)[NR_COST + 1]);
+            unsigned int hh = key_hash(k2) & hmask;
+            for (int guard = 0; guard < p.hash_cap; ++guard) {
+              if (atomicCAS(&tab[hh], 0, si + 1) == 0) break;
+              hh = (hh + 1) & hmask;
+            }
+          }
+        }
+        wave_sync_global();
+        lds_dict = false;
+        h = h32 & hmask;  // the probes of this batch ended in the LDS dict: the inserts below start at the key's home bucket
       }
       if (is_leader && !exists) {
-#ifdef D2D_SEARCH_PLAIN
-        unsigned int hh = key_hash(key) & hmask;
-        for (int guard = 0; guard < p.hash_cap; ++guard) {
-          if (atomicCAS(&tab[hh], 0, myslot + 1) == 0) break;
-          hh = (hh + 1) & hmask;
+        if (lds_dict) {
+          // the probe ended at an empty entry `h`: two entries share a dword, another successor may be taking either of them right
+          // now -- compare-and-swap on the dword, on from the next entry when this one has been taken
+          const unsigned int ent = (((h32 >> 17) & 0x1fu) << 11) | (unsigned int)(myslot + 1);
+          unsigned int *lh32 = (unsigned int *)S.lh;
+          for (int guard = 0; guard < 4 * LH_N; ++guard) {
+            const unsigned int sh = (h & 1u) * 16u;
+            const unsigned int w = lh32[h >> 1];
+            if (((w >> sh) & 0xffffu) != 0u) {
+              h = (h + 1u) & (LH_N - 1u);
+              continue;
+            }
+            if (atomicCAS(&lh32[h >> 1], w, w | (ent << sh)) == w) break;
+          }
+        } else {
+          unsigned int hh = h;
+          for (int guard = 0; guard < p.hash_cap; ++guard) {
+            if (atomicCAS(&tab[hh], 0, myslot + 1) == 0) break;
+            hh = (hh + 1) & hmask;
+          }
         }
-#else
-        // the probe ended at an empty bucket `h`: the swap goes there, and its result is looked at only before the next probe
-        // (top of the next batch): the round trip overlaps the next argmin instead of stalling this expansion
-        pend_h = h;
-        pend_val = myslot + 1;
-        pend_old = atomicCAS(&tab[h], 0, pend_val);
-        pend = true;
-#endif
       }
       nn += nnew;
       open_n += nnew;
       SP_T(sp7);
       SP_ADD(6, sp6, sp7);
-      // a further batch of this expansion probes what this one wrote: full hand-off; after the last batch only the LDS mirror
-      // has to be in order -- the global hand-off waits until the next argmin has scanned it (see there)
+      // a further batch of this expansion probes what this one wrote: full hand-off; after the last batch only LDS (cost mirror,
+      // dict) has to be in order -- the global hand-off waits until the next argmin has scanned the mirror (see there)
       if (p0 + WAVE < nprim) wave_sync_global();
       else wave_sync_lds();
       SP_T(sp8);
@@ -683,7 +734,7 @@ __device__ int plan_search(const d2d_cfg &c, const d2d_state &s, const d2d_plan 
   SP_T(spa);
   // ---- :207-216: waypoints of every primitive on the path, start side first ----
   int depth = 0;
-  for (int q = goal; q != 0 && depth <= 128; q = nd.link[q].x) depth += 1;  // bounded: a wave must always terminate
+  for (int q = goal; q != 0 && depth <= 128; q = meta_parent(nd.rec(q)[NR_META])) depth += 1;  // bounded: a wave must always terminate
   if (depth * p.n_ts > p.traj_cap || depth > 128) {
     if (lane == 0) stat[3] = 1;
     return -1;
@@ -692,7 +743,7 @@ __device__ int plan_search(const d2d_cfg &c, const d2d_state &s, const d2d_plan 
     int q = goal;
     for (int lvl = depth - 1; lvl >= 0; --lvl) {
       chain[lvl] = q;
-      q = nd.link[q].x;
+      q = meta_parent(nd.rec(q)[NR_META]);
     }
   }
   wave_sync_lds();
@@ -701,15 +752,18 @@ __device__ int plan_search(const d2d_cfg &c, const d2d_state &s, const d2d_plan 
     const int w = w0 + lane;
     if (w < total) {
       const int lvl = w / p.n_ts, mi = w - lvl * p.n_ts;
-      const int q = chain[lvl], par = nd.link[q].x;
-      const double hx = nd.ax[q] / 2, hy = nd.ay[q] / 2;
+      const int q = chain[lvl];
+      const double *rq = nd.rec(q);
+      const int par = meta_parent(rq[NR_META]);
+      const double2 acc = ld2(rq + NR_ACC);
+      const double hx = acc.x / 2, hy = acc.y / 2;
       const double t = p.traj_t[3 * mi], t2 = p.traj_t[3 * mi + 1], tt = p.traj_t[3 * mi + 2];
-      const double ppx = nd.px[par], ppy = nd.py[par], pvx = nd.vx[par], pvy = nd.vy[par];
+      const double2 pp = ld2(nd.rec(par) + NR_POS), pv = ld2(nd.rec(par) + NR_VEL);
       double *o = traj + (size_t)w * 4;
-      o[0] = rint(__builtin_fma(t2, hx, ppx + t * pvx));  // :121
-      o[1] = rint(__builtin_fma(t2, hy, ppy + t * pvy));
-      o[2] = pvx + tt * hx;                               // :122
-      o[3] = pvy + tt * hy;
+      o[0] = rint(__builtin_fma(t2, hx, pp.x + t * pv.x));  // :121
+      o[1] = rint(__builtin_fma(t2, hy, pp.y + t * pv.y));
+      o[2] = pv.x + tt * hx;                                // :122
+      o[3] = pv.y + tt * hy;
     }
   }
   SP_T(spb);
@@ -721,12 +775,12 @@ __device__ int plan_search(const d2d_cfg &c, const d2d_state &s, const d2d_plan 
   return total;
 }
 
-// LDS per wave of k_plan: 6 planes of ncap doubles (active trackers) + the search's hand-off arrays
-__host__ __device__ inline int plan_wave_bytes(int N, int nu, int n_sample, int WH) {
+// LDS per wave of k_plan: 5 planes of ncap doubles (active trackers) + the search's hand-off arrays, cost mirror, wall rows, dict
+__host__ __device__ inline int plan_wave_bytes(int N, int nu, int n_sample, int W, int H) {
   const int ncap = ((N > 0 ? N : 1) + 3) & ~3;
   const int nu4 = ((nu + 3) & ~3) + ((nu * nu + 3) & ~3), ns4 = (2 * n_sample + 3) & ~3;  // u_space + the primitives' cost terms
-  const int mapb = WH <= D2D_SEARCH_LDS_MAP ? ((WH + 15) & ~15) : 0;
-  return 5 * 8 * ncap + 8 * (nu4 + ns4) + 8 * 64 + 8 * 64 + 4 * 64 + 128 * 4 + 16 + 8 * search_lds_nodes(N) + mapb;
+  const int rowb = search_wall_rows(W, H) ? 8 * 64 : 0;
+  return 5 * 8 * ncap + 8 * (nu4 + ns4) + 8 * 64 + 8 * 64 + 4 * 64 + 128 * 4 + 16 + 8 * search_lds_nodes(N) + rowb + 2 * LH_N;
 }
 
 // replan_check + plan + head waypoint of env e by one wave; `base`: plan_wave_bytes() bytes of LDS
@@ -747,7 +801,9 @@ __device__ __forceinline__ void plan_carve(const d2d_cfg &c, const d2d_plan &p, 
   S.misc = S.chain + 128;
   S.tot = (double *)(S.misc + 4);
   S.ntot = search_lds_nodes(N);
-  S.map = (c.W * c.H <= D2D_SEARCH_LDS_MAP) ? (unsigned char *)(S.tot + S.ntot) : nullptr;
+  unsigned long long *after = (unsigned long long *)(S.tot + S.ntot);
+  S.prow = search_wall_rows(c.W, c.H) ? after : nullptr;
+  S.lh = (unsigned short *)(after + (search_wall_rows(c.W, c.H) ? 64 : 0));
 }
 
 // Writes the head step_pos will consume (utils.py:733-739) and the planner's result; pops the head.
@@ -906,7 +962,7 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK) void k_plan(d2d_cfg c, d2d_s
   const int e = blockIdx.x * (int)(blockDim.x / WAVE) + wv;
   if (e >= c.B) return;
   if (skip_done && s.flags[(size_t)e * 4 + D2D_F_DONE] != 0) return;
-  plan_env(c, s, p, e, lane, d2d_lds + (size_t)wv * plan_wave_bytes(c.N, p.nu, p.n_sample, c.W * c.H));
+  plan_env(c, s, p, e, lane, d2d_lds + (size_t)wv * plan_wave_bytes(c.N, p.nu, p.n_sample, c.W, c.H));
 }
 
 // ------------------------------------------------------------------------------------------------
