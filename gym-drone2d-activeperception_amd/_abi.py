@@ -31,7 +31,7 @@ DONE_CONTINUE, DONE_RESET, DONE_FREEZE = 0, 1, 2
 class Cfg(C.Structure):
     _fields_ = [(n, C.c_int32) for n in
                 ('abi_version', 'B', 'N', 'W', 'H', 'R', 'L', 'T', 'planner_mode', 'kf_enabled',
-                 'noise_rows', 'noise_row0')] + \
+                 'noise_rows', 'noise_row0', 'grid_tile', 'reserved2')] + \
                [(n, C.c_double) for n in
                 ('dt', 'scale', 'W_px', 'H_px', 'ray_off0', 'ray_dth', 'depth', 'drone_radius', 'yaw_rate',
                  'max_acc', 'max_steps', 'sigma', 'kf_lo_x', 'kf_hi_x', 'kf_lo_y', 'kf_hi_y')]

@@ -43,6 +43,7 @@ def load_library(path=LIB_PATH):
 class HipBackend:
     """Thin call surface over the C ABI; launches go to torch's current HIP stream of `device`."""
     name = 'hip'
+    supports_tiled_grids = True      # d2d_cfg.grid_tile = 16 (the CPU oracle keeps the reference's row-major grids)
 
     def __init__(self, device='cuda:0'):
         import torch

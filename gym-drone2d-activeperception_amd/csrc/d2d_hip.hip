@@ -262,6 +262,28 @@ struct CellDiv {
   }
 };
 
+// Byte offset of cell (i, j) inside one env's grid (d2d_cfg.grid_tile).  Row-major [W][H] (the reference's indexing, utils.py:548,
+// and the ABI default), or -- TILED -- 16 x 16-cell tiles of 256 contiguous bytes, tiles row-major over (ceil(W / 16), ceil(H / 16)),
+// cells row-major inside a tile: on grids of hundreds of cells a side every 3 x 3 block, 23-byte window row and 33-byte crop row of
+// the row-major layout costs a cache line of its own (640-byte row stride); tiled, a 3 x 3 block lies in one or two lines, a 23 x 23
+// window in at most nine tiles.  0 <= i < W, 0 <= j < H.
+template <bool TILED>
+struct GridIx {
+  static constexpr bool tiled = TILED;
+  int H, Ht;
+  __device__ __forceinline__ int operator()(int i, int j) const {
+    if constexpr (TILED) return ((((i >> 4) * Ht + (j >> 4)) << 8) | ((i & 15) << 4) | (j & 15));
+    else return i * H + j;
+  }
+};
+__host__ __device__ inline size_t grid_bytes(const d2d_cfg &c) {
+  return c.grid_tile ? (size_t)((c.W + 15) >> 4) * (size_t)((c.H + 15) >> 4) * 256 : (size_t)c.W * c.H;
+}
+// run-time form for the few grid reads of the plugin stages
+__device__ __forceinline__ int grid_ix(const d2d_cfg &c, int i, int j) {
+  return c.grid_tile ? ((((i >> 4) * ((c.H + 15) >> 4) + (j >> 4)) << 8) | ((i & 15) << 4) | (j & 15)) : i * c.H + j;
+}
+
 // ------------------------------------------------------------------------------------------------
 // LDS tiles of a uint8 grid
 // ------------------------------------------------------------------------------------------------
@@ -283,7 +305,8 @@ __device__ __forceinline__ Tile make_tile(int i0, int j0, int rows, int cols) {
 // Two tiles at once, two rows per wave instruction: lanes 0-31 take row 2t, lanes 32-63 row 2t + 1, lane & 31 is
 // the column (tile A: cols <= 32; tile B: cols <= 33, its column 32 is swept by a last pass with lane = row).
 // MAXA / MAXB bound the row pairs held in registers (12 and 17: 23- and 33-row tiles).
-__device__ __forceinline__ void tile_rows2(const Tile &ta, unsigned char *la, const unsigned char *__restrict__ ga, int W,
+template <typename GX>
+__device__ __forceinline__ void tile_rows2(const GX &gx, const Tile &ta, unsigned char *la, const unsigned char *__restrict__ ga, int W,
                                            int H, int lane, unsigned char fa, const Tile &tb, unsigned char *lb,
                                            const unsigned char *__restrict__ gb, unsigned char fb) {
   constexpr int MAXA = 12, MAXB = 17;
@@ -295,7 +318,7 @@ __device__ __forceinline__ void tile_rows2(const Tile &ta, unsigned char *la, co
 #pragma unroll
     for (int t = 0; t < MAXA; ++t) {
       const int r = 2 * t + half, i = ta.i0 + r;
-      const unsigned char g = ga[min(max(i, 0), W - 1) * H + jc];
+      const unsigned char g = ga[gx(min(max(i, 0), W - 1), jc)];
       va[t] = (jok && i >= 0 && i < W) ? g : fa;
     }
   }
@@ -305,12 +328,12 @@ __device__ __forceinline__ void tile_rows2(const Tile &ta, unsigned char *la, co
 #pragma unroll
     for (int t = 0; t < MAXB; ++t) {
       const int r = 2 * t + half, i = tb.i0 + r;
-      const unsigned char g = gb[min(max(i, 0), W - 1) * H + jc];
+      const unsigned char g = gb[gx(min(max(i, 0), W - 1), jc)];
       vb[t] = (jok && i >= 0 && i < W) ? g : fb;
     }
     if (tb.cols > 32) {  // column 32 of every row, lane = row
       const int i = tb.i0 + lane, j32 = tb.j0 + 32;
-      const unsigned char g = gb[min(max(i, 0), W - 1) * H + min(max(j32, 0), H - 1)];
+      const unsigned char g = gb[gx(min(max(i, 0), W - 1), min(max(j32, 0), H - 1))];
       vc = (i >= 0 && i < W && j32 >= 0 && j32 < H) ? g : fb;
     }
   }
@@ -328,8 +351,8 @@ __device__ __forceinline__ void tile_rows2(const Tile &ta, unsigned char *la, co
 }
 
 // loads of up to CH x 64 cells are issued back to back, then written to LDS
-template <int CH>
-__device__ __forceinline__ void tile_load(const Tile &t, unsigned char *lds, const unsigned char *__restrict__ grid, int W,
+template <int CH, typename GX>
+__device__ __forceinline__ void tile_load(const GX &gx, const Tile &t, unsigned char *lds, const unsigned char *__restrict__ grid, int W,
                                           int H, int lane, unsigned char fill) {
   const FastDiv fd(t.cols);
   const int n = t.rows * t.cols;
@@ -341,7 +364,7 @@ __device__ __forceinline__ void tile_load(const Tile &t, unsigned char *lds, con
       int r, q;
       fd.divmod(idx, r, q);
       const int i = t.i0 + r, j = t.j0 + q;
-      const unsigned char g = grid[min(max(i, 0), W - 1) * H + min(max(j, 0), H - 1)];
+      const unsigned char g = grid[gx(min(max(i, 0), W - 1), min(max(j, 0), H - 1))];
       v[u] = (i >= 0 && i < W && j >= 0 && j < H) ? g : fill;
     }
 #pragma unroll
@@ -644,8 +667,8 @@ __device__ __forceinline__ RayT<M> ray_setup(const d2d_cfg &c, const LdsView &L,
 // GENERAL: some ray of the wave has more than one candidate (or the env more than 32): the per-sample LDS
 // candidate loops are compiled in.  The common instantiation tests only the register-held first candidate.
 // FULL: L.gtw / L.dmt are copies of the WHOLE grids (Geom.full), indexed by the cell itself -- no window / crop arithmetic.
-template <bool GENERAL, bool FULL, typename M>
-__device__ __forceinline__ void ray_march(const d2d_cfg &c, const Geom &g, const LdsView &L, const RayT<M> &ry, bool active,
+template <bool GENERAL, bool FULL, typename M, typename GX>
+__device__ __forceinline__ void ray_march(const GX &gx, const d2d_cfg &c, const Geom &g, const LdsView &L, const RayT<M> &ry, bool active,
                                           int ncand, double x0, double y0, const Tile &wt, const Tile &ct, bool patch,
                                           unsigned char *__restrict__ dm) {
   const int H = c.H;
@@ -730,7 +753,7 @@ __device__ __forceinline__ void ray_march(const d2d_cfg &c, const Geom &g, const
         if (patch) dmt[gi] = v;  // the copy the observation crop is cut from
       } else {
 #ifndef D2D_ABL_NOSTORE
-        dm[ci * H + cj] = v;
+        dm[gx(ci, cj)] = v;
 #endif
         const unsigned int pr = (unsigned int)(ci - ct.i0), pq = (unsigned int)(cj - ct.j0);  // observation tile in step
         if (patch && pr < (unsigned int)ct.rows && pq < (unsigned int)ct.cols) dmt[pr * ct.cols + pq] = v;
@@ -790,8 +813,8 @@ __device__ __forceinline__ unsigned int block_valid9(int cx, int cy, int u, int 
 
 // PREV / NEW: which of the two blocks are fetched (both for the one-pass update; the two-phase update of large grids fetches the
 // previous block before its first phase and the new block, again, after the fence between the phases).
-template <bool PREV = true, bool NEW = true>
-__device__ __forceinline__ void dyn_load(const d2d_cfg &c, const unsigned char *__restrict__ gt, int k, const LdsView &L,
+template <bool PREV = true, bool NEW = true, typename GX>
+__device__ __forceinline__ void dyn_load(const GX &gx, const d2d_cfg &c, const unsigned char *__restrict__ gt, int k, const LdsView &L,
                                          DynCells &dc) {
   const int W = c.W, H = c.H;
   const int pcx = L.pcx[k], pcy = L.pcy[k], pu = L.pu[k], ncx = L.ncx[k], ncy = L.ncy[k], nu = L.nu[k];
@@ -802,19 +825,28 @@ __device__ __forceinline__ void dyn_load(const d2d_cfg &c, const unsigned char *
   if (__all(interior || !small)) {
     // every 3 x 3 block of the wave lies inside the grid (agents keep a radius away from the border): one
     // address per block, the nine cells at constant offsets
-    const unsigned char *pp = gt + (interior ? pcx * H + pcy : H + 1), *np = gt + (interior ? ncx * H + ncy : H + 1);
+    if constexpr (GX::tiled) {
+      const int pi = interior ? pcx : 1, pj = interior ? pcy : 1, ni = interior ? ncx : 1, nj = interior ? ncy : 1;
 #pragma unroll
-    for (int q = 0; q < 9; ++q) {
-      const int o = (q / 3 - 1) * H + (q % 3 - 1);
-      pv[q] = PREV ? pp[o] : (unsigned char)0;
-      nv[q] = NEW ? np[o] : (unsigned char)D2D_OCCUPIED;
+      for (int q = 0; q < 9; ++q) {
+        pv[q] = PREV ? gt[gx(pi + q / 3 - 1, pj + q % 3 - 1)] : (unsigned char)0;
+        nv[q] = NEW ? gt[gx(ni + q / 3 - 1, nj + q % 3 - 1)] : (unsigned char)D2D_OCCUPIED;
+      }
+    } else {
+      const unsigned char *pp = gt + (interior ? pcx * H + pcy : H + 1), *np = gt + (interior ? ncx * H + ncy : H + 1);
+#pragma unroll
+      for (int q = 0; q < 9; ++q) {
+        const int o = (q / 3 - 1) * H + (q % 3 - 1);
+        pv[q] = PREV ? pp[o] : (unsigned char)0;
+        nv[q] = NEW ? np[o] : (unsigned char)D2D_OCCUPIED;
+      }
     }
   } else {
 #pragma unroll
     for (int q = 0; q < 9; ++q) {  // clamped (always valid) addresses
       const int di = q / 3 - 1, dj = q % 3 - 1;
-      pv[q] = PREV ? gt[min(max(pcx + di, 0), W - 1) * H + min(max(pcy + dj, 0), H - 1)] : (unsigned char)0;
-      nv[q] = NEW ? gt[min(max(ncx + di, 0), W - 1) * H + min(max(ncy + dj, 0), H - 1)] : (unsigned char)D2D_OCCUPIED;
+      pv[q] = PREV ? gt[gx(min(max(pcx + di, 0), W - 1), min(max(pcy + dj, 0), H - 1))] : (unsigned char)0;
+      nv[q] = NEW ? gt[gx(min(max(ncx + di, 0), W - 1), min(max(ncy + dj, 0), H - 1))] : (unsigned char)D2D_OCCUPIED;
     }
   }
   unsigned int pdyn = 0, nfree = 0;
@@ -845,8 +877,8 @@ __device__ __forceinline__ void dyn_load(const d2d_cfg &c, const unsigned char *
 // whatever a neighbour cleared in phase 1.  Same final grid as the reference's clear-everything-then-mark (a cell that is not
 // static ends DYNAMIC iff some new block covers it, and a cell that held DYNAMIC and is covered by nobody lies in a previous
 // block whose owner clears it), with no coverage structure: no LDS, no inserts, no lookups.
-template <int PHASE>
-__device__ __forceinline__ void dyn_apply(const d2d_cfg &c, const d2d_state &s, int e, int k, const Geom &g,
+template <int PHASE, typename GX>
+__device__ __forceinline__ void dyn_apply(const GX &gx, const d2d_cfg &c, const d2d_state &s, int e, int k, const Geom &g,
                                           const LdsView &L, unsigned char *__restrict__ gt, const DynCells &dc) {
   const int N = c.N, W = c.W, H = c.H;
   int *prev = s.dyn_prev + (size_t)e * N * 3;
@@ -864,7 +896,7 @@ __device__ __forceinline__ void dyn_apply(const d2d_cfg &c, const d2d_state &s, 
         const int q = __ffs((int)m) - 1;
         m &= m - 1;
         const int i = pcx + q / 3 - 1, j = pcy + q % 3 - 1;
-        if (PHASE == 1 || !covered(i, j)) gt[i * H + j] = D2D_UNOCCUPIED;
+        if (PHASE == 1 || !covered(i, j)) gt[gx(i, j)] = D2D_UNOCCUPIED;
       }
     }
     if (PHASE != 1) {
@@ -872,7 +904,7 @@ __device__ __forceinline__ void dyn_apply(const d2d_cfg &c, const d2d_state &s, 
       while (m) {
         const int q = __ffs((int)m) - 1;
         m &= m - 1;
-        gt[(ncx + q / 3 - 1) * H + (ncy + q % 3 - 1)] = D2D_DYNAMIC;
+        gt[gx(ncx + q / 3 - 1, ncy + q % 3 - 1)] = D2D_DYNAMIC;
       }
     }
   } else {
@@ -880,14 +912,14 @@ __device__ __forceinline__ void dyn_apply(const d2d_cfg &c, const d2d_state &s, 
       const int i1 = min(pcx + pu + 1, W), j1 = min(pcy + pu + 1, H);
       for (int i = max(pcx - pu, 0); i < i1; ++i)
         for (int j = max(pcy - pu, 0); j < j1; ++j)
-          if (gt[i * H + j] == D2D_DYNAMIC && !covered(i, j)) gt[i * H + j] = D2D_UNOCCUPIED;
+          if (gt[gx(i, j)] == D2D_DYNAMIC && !covered(i, j)) gt[gx(i, j)] = D2D_UNOCCUPIED;
     }
     if (PHASE != 1) {
       const int i3 = min(ncx + nu + 1, W), j3 = min(ncy + nu + 1, H);
       for (int i = max(ncx - nu, 0); i < i3; ++i)
         for (int j = max(ncy - nu, 0); j < j3; ++j) {
-          const unsigned char v = gt[i * H + j];
-          if (v != D2D_OCCUPIED && v != D2D_DYNAMIC) gt[i * H + j] = D2D_DYNAMIC;
+          const unsigned char v = gt[gx(i, j)];
+          if (v != D2D_OCCUPIED && v != D2D_DYNAMIC) gt[gx(i, j)] = D2D_DYNAMIC;
         }
     }
   }
@@ -1305,7 +1337,7 @@ __device__ __forceinline__ void store_regs(const d2d_state &s, int e, const EnvR
 // FULL (Geom.full, the specialised 50 x 50 geometry): both grids are staged WHOLE in LDS by DMA in batch 1 -- there is no
 // batch 2 at all: rays, collision probes, the dynamic-grid update and the observation crop read the copies.
 // WIDE: 64 ray candidates on the mask path (spec_wide).  CONE: candidates culled against the cone of the rays (spec_cone).
-template <bool FULL, bool WIDE, bool CONE>
+template <bool FULL, bool WIDE, bool CONE, bool TILED = false>
 __device__ __forceinline__ void run_env(const d2d_cfg &c, const d2d_state &s, int e, int lane, uint32_t stages,
                                         const Geom &g, const LdsView &L, double action, EnvRegs &r, size_t noise_off = 0) {
   using RayMask = std::conditional_t<WIDE, unsigned long long, unsigned int>;
@@ -1313,8 +1345,10 @@ __device__ __forceinline__ void run_env(const d2d_cfg &c, const d2d_state &s, in
   const double inv_scale = 1.0 / c.scale;
   const bool do_ray = stages & D2D_ST_RAYCAST, do_dyn = stages & D2D_ST_DYNGRID, do_trk = stages & D2D_ST_TRACKER;
   const bool do_col = stages & D2D_ST_COLLIDE, do_obs = stages & D2D_ST_OBS, do_ctl = stages & D2D_ST_CONTROL;
-  unsigned char *__restrict__ gt = s.gt + (size_t)e * W * H;
-  unsigned char *__restrict__ dm = s.dmap + (size_t)e * W * H;
+  const GridIx<TILED> gx = {H, (H + 15) >> 4};
+  const size_t gbytes = TILED ? (size_t)((W + 15) >> 4) * (size_t)((H + 15) >> 4) * 256 : (size_t)W * H;
+  unsigned char *__restrict__ gt = s.gt + (size_t)e * gbytes;
+  unsigned char *__restrict__ dm = s.dmap + (size_t)e * gbytes;
 
   // ---------------- batch 1 ----------------
   const bool gt_staged = FULL && (do_ray || do_dyn);  // the five collision probes alone read global memory directly
@@ -1357,22 +1391,22 @@ __device__ __forceinline__ void run_env(const d2d_cfg &c, const d2d_state &s, in
     const double qx = r.x + ox, qy = r.y + oy;
     const bool oob = (qx >= c.W_px || qx < 0.0 || qy >= c.H_px || qy < 0.0);
     const int pi = min(max(cell_fast(qx, c.scale, inv_scale), 0), W - 1), pj = min(max(cell_fast(qy, c.scale, inv_scale), 0), H - 1);
-    probe_wall = oob || gt[pi * H + pj] == D2D_OCCUPIED;
+    probe_wall = oob || gt[gx(pi, pj)] == D2D_OCCUPIED;
   }
   if constexpr (!FULL) {
     if (do_ray && do_obs && wt.cols <= 32 && wt.rows <= 24 && ct.cols <= 33 && ct.rows <= 34) {
       // default geometry (23 x 23 window, 33 x 33 crop): lanes map to (row parity, column), so a cell costs an
       // add and a compare instead of a division; all loads of both tiles are in flight before the first LDS write
-      tile_rows2(wt, (unsigned char *)L.gtw, gt, W, H, lane, (unsigned char)D2D_OCCUPIED,
+      tile_rows2(gx, wt, (unsigned char *)L.gtw, gt, W, H, lane, (unsigned char)D2D_OCCUPIED,
                  ct, (unsigned char *)L.dmt, dm, (unsigned char)0);
     } else {
-      if (do_ray) tile_load<9>(wt, (unsigned char *)L.gtw, gt, W, H, lane, (unsigned char)D2D_OCCUPIED);
-      if (do_obs) tile_load<9>(ct, (unsigned char *)L.dmt, dm, W, H, lane, (unsigned char)0);
+      if (do_ray) tile_load<9>(gx, wt, (unsigned char *)L.gtw, gt, W, H, lane, (unsigned char)D2D_OCCUPIED);
+      if (do_obs) tile_load<9>(gx, ct, (unsigned char *)L.dmt, dm, W, H, lane, (unsigned char)0);
     }
     if (do_dyn) dyn_bitmap(c, lane, g, L);
     if (dyn_fast && lane < N) {
-      if (g.dyn2p) dyn_load<true, false>(c, gt, lane, L, dc);
-      else dyn_load(c, gt, lane, L, dc);
+      if (g.dyn2p) dyn_load<true, false>(gx, c, gt, lane, L, dc);
+      else dyn_load(gx, c, gt, lane, L, dc);
     }
   }
 
@@ -1439,7 +1473,7 @@ __device__ __forceinline__ void run_env(const d2d_cfg &c, const d2d_state &s, in
           const unsigned char v0 = (w0 == D2D_OCCUPIED) ? (unsigned char)D2D_OCCUPIED : (unsigned char)D2D_UNOCCUPIED;
           if (lane == 0) {
 #ifndef D2D_ABL_NOSTORE
-            dm[ocx * H + ocy] = v0;
+            dm[gx(ocx, ocy)] = v0;
 #endif
             if constexpr (FULL) {
               if (do_obs) ((unsigned char *)L.dmt)[g0] = v0;
@@ -1452,8 +1486,8 @@ __device__ __forceinline__ void run_env(const d2d_cfg &c, const d2d_state &s, in
         }
       }
       const bool general = ncand > (int)(8 * sizeof(RayMask)) || __any((ry.cmask & (ry.cmask - (RayMask)1)) != (RayMask)0);
-      if (general) ray_march<true, FULL>(c, g, L, ry, go && i < c.R, ncand, x0, y0, wt, ct, do_obs, dm);
-      else ray_march<false, FULL>(c, g, L, ry, go && i < c.R, ncand, x0, y0, wt, ct, do_obs, dm);
+      if (general) ray_march<true, FULL>(gx, c, g, L, ry, go && i < c.R, ncand, x0, y0, wt, ct, do_obs, dm);
+      else ray_march<false, FULL>(gx, c, g, L, ry, go && i < c.R, ncand, x0, y0, wt, ct, do_obs, dm);
     }
     wave_sync_lds();
     D2D_STAMP(6);
@@ -1486,26 +1520,26 @@ __device__ __forceinline__ void run_env(const d2d_cfg &c, const d2d_state &s, in
     if constexpr (FULL) {
       dyn_full(c, s, e, lane, L, gt);
     } else if (g.dyn2p) {  // grids above 256 x 256 cells: clear, fence, fetch again and mark (dyn_apply)
-      if (lane < N) dyn_apply<1>(c, s, e, lane, g, L, gt, dc);
+      if (lane < N) dyn_apply<1>(gx, c, s, e, lane, g, L, gt, dc);
       for (int k = WAVE + lane; k < N; k += WAVE) {
         DynCells dk;
-        dyn_load<true, false>(c, gt, k, L, dk);
-        dyn_apply<1>(c, s, e, k, g, L, gt, dk);
+        dyn_load<true, false>(gx, c, gt, k, L, dk);
+        dyn_apply<1>(gx, c, s, e, k, g, L, gt, dk);
       }
       wave_sync_global();
       for (int k = lane; k < N; k += WAVE) {
         DynCells dk;
-        dyn_load<false, true>(c, gt, k, L, dk);
-        dyn_apply<2>(c, s, e, k, g, L, gt, dk);
+        dyn_load<false, true>(gx, c, gt, k, L, dk);
+        dyn_apply<2>(gx, c, s, e, k, g, L, gt, dk);
       }
     } else {
-      if (lane < N) dyn_apply<0>(c, s, e, lane, g, L, gt, dc);
+      if (lane < N) dyn_apply<0>(gx, c, s, e, lane, g, L, gt, dc);
       // more than 64 agents: every further pass fetches the 18 cells of its 64 agents together (one round trip), then applies.
       // A later pass may read cells an earlier one has already written: the rule is order-independent (see dyn_apply).
       for (int k = WAVE + lane; k < N; k += WAVE) {
         DynCells dk;
-        dyn_load(c, gt, k, L, dk);
-        dyn_apply<0>(c, s, e, k, g, L, gt, dk);
+        dyn_load(gx, c, gt, k, L, dk);
+        dyn_apply<0>(gx, c, s, e, k, g, L, gt, dk);
       }
     }
   }
@@ -1546,14 +1580,17 @@ __host__ __device__ constexpr bool spec_full(int spec) { return spec == 1 || spe
 // on 500 x 500 px).  Not the generic kernel: it is at its scalar-register limit (the per-lane predicates of the march live in
 // SGPR pairs) and the wider mask costs config 5 -- 100 agents on 6400 x 6400 px, hardly ever a candidate -- a quarter of its
 // raycast time in spilled scalars.
-__host__ __device__ constexpr bool spec_wide(int spec) { return spec == 3 || spec == 0; }
+__host__ __device__ constexpr bool spec_wide(int spec) { return spec == 3 || spec == 0 || spec == 4; }
+// SPEC 4: the generic kernel on tiled grids (d2d_cfg.grid_tile, GridIx)
+__host__ __device__ constexpr bool spec_tiled(int spec) { return spec == 4; }
+__host__ __device__ constexpr bool spec_generic(int spec) { return spec == 0 || spec == 4; }
 // ray candidates culled against the cone of the rays (ray_cull<true>): where an env has enough agents for it to pay
 __host__ __device__ constexpr bool spec_cone(int spec) { return spec != 1; }
 __host__ __device__ inline bool spec_default_matches(const d2d_cfg &c) {
   return c.W == 50 && c.H == 50 && c.R == 50 && c.L == 33 && c.dt == 0.1 && c.scale == 10.0 &&
          c.W_px == 500.0 && c.H_px == 500.0 && c.ray_off0 == -0x1.921fb54442d18p-1 && c.ray_dth == 0x1.015bf9217271ap-5 &&
          c.depth == 80.0 && c.drone_radius == 10.0 && c.yaw_rate == 80.0 && c.max_acc == 40.0 && c.max_steps == 800.0 &&
-         c.sigma == 0.0;
+         c.sigma == 0.0 && c.grid_tile == 0;
 }
 
 __device__ __forceinline__ void spec_default_apply(d2d_cfg &c) {
@@ -1561,6 +1598,7 @@ __device__ __forceinline__ void spec_default_apply(d2d_cfg &c) {
   c.dt = 0.1; c.scale = 10.0; c.W_px = 500.0; c.H_px = 500.0;
   c.ray_off0 = -0x1.921fb54442d18p-1; c.ray_dth = 0x1.015bf9217271ap-5;
   c.depth = 80.0; c.drone_radius = 10.0; c.yaw_rate = 80.0; c.max_acc = 40.0; c.max_steps = 800.0; c.sigma = 0.0;
+  c.grid_tile = 0;
 }
 
 extern __shared__ __attribute__((aligned(16))) char d2d_lds[];
@@ -1593,11 +1631,11 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK, D2D_MIN_WAVES) void k_stages
   const double *pin = args.pin;
   unsigned char *coll_out = args.coll_out;
   d2d_cfg c_folded;
-  if (SPEC != 0) {
+  if (!spec_generic(SPEC)) {
     c_folded = c_in;
     spec_default_apply(c_folded);
   }
-  const d2d_cfg &c = SPEC != 0 ? c_folded : ka->c;
+  const d2d_cfg &c = !spec_generic(SPEC) ? c_folded : ka->c;
   const d2d_state &s = (SPEC == 1 || SPEC == 2) ? s_in : ka->s;  // the many-agent kernel folds cfg, but its state pointers spill too
   // wave-uniform by construction; readfirstlane tells the compiler, so every per-env base pointer and LDS
   // base lives in SGPRs and loads take the scalar-base + 32-bit-offset form
@@ -1621,7 +1659,7 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK, D2D_MIN_WAVES) void k_stages
     r.x = pin[(size_t)e * 2];
     r.y = pin[(size_t)e * 2 + 1];
   }
-  run_env<spec_full(SPEC), spec_wide(SPEC), spec_cone(SPEC)>(c, s, e, lane, stages, g, L, s.action[e], r);
+  run_env<spec_full(SPEC), spec_wide(SPEC), spec_cone(SPEC), spec_tiled(SPEC)>(c, s, e, lane, stages, g, L, s.action[e], r);
   if (lane == 0) {
     store_regs(s, e, r);
     if (coll_out) coll_out[e] = s.flags[(size_t)e * 4 + D2D_F_COLLISION];
@@ -1631,7 +1669,7 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK, D2D_MIN_WAVES) void k_stages
 
 // reset(): copy of the snapshot over the live state of env e by one wave
 __device__ __forceinline__ void reset_env(const d2d_cfg &c, const d2d_state &s, const d2d_state &init, size_t e, int lane) {
-  const size_t N = c.N, WH = (size_t)c.W * c.H, LL = (size_t)c.L * c.L;
+  const size_t N = c.N, WH = grid_bytes(c), LL = (size_t)c.L * c.L;
   for (size_t i = lane; i < D2D_AF * N; i += WAVE) s.agents[e * D2D_AF * N + i] = init.agents[e * D2D_AF * N + i];
   for (size_t i = lane; i < N; i += WAVE) {
     s.agent_unit[e * N + i] = init.agent_unit[e * N + i];
@@ -1748,7 +1786,7 @@ __device__ __attribute__((noinline)) int ph_plan_quick(const ClosedArgs *ap, int
   const int e = __builtin_amdgcn_readfirstlane(e_), lane = threadIdx.x & (WAVE - 1);
   char *base = d2d_lds + __builtin_amdgcn_readfirstlane(lds_off_);
   d2d_cfg c = a->c;
-  if (SPEC != 0) spec_default_apply(c);
+  if (!spec_generic(SPEC)) spec_default_apply(c);
   if constexpr (SPEC == 1 || SPEC == 2) {  // folds the size of the search's cost mirror (search_lds_nodes)
     constexpr int cap = spec_ncap(SPEC);
     __builtin_assume(c.N <= cap);
@@ -1764,7 +1802,7 @@ __device__ __attribute__((noinline)) void ph_plan_search(const ClosedArgs *ap, i
   const int e = __builtin_amdgcn_readfirstlane(e_), lane = threadIdx.x & (WAVE - 1);
   char *base = d2d_lds + __builtin_amdgcn_readfirstlane(lds_off_);
   d2d_cfg c = a->c;
-  if (SPEC != 0) spec_default_apply(c);
+  if (!spec_generic(SPEC)) spec_default_apply(c);
   if constexpr (SPEC == 1 || SPEC == 2) {  // folds the size of the search's cost mirror (search_lds_nodes)
     constexpr int cap = spec_ncap(SPEC);
     __builtin_assume(c.N <= cap);
@@ -1781,7 +1819,7 @@ __device__ __attribute__((noinline)) void ph_gaze_stages(const ClosedArgs *ap, i
   const int tstep = __builtin_amdgcn_readfirstlane(t_);
   char *base = d2d_lds + __builtin_amdgcn_readfirstlane(lds_off_);
   d2d_cfg c = a->c;
-  if (SPEC != 0) spec_default_apply(c);
+  if (!spec_generic(SPEC)) spec_default_apply(c);
   gaze_env(c, a->s, a->p, a->init, a->on_done == D2D_DONE_RESET, e, lane, base);
   wave_sync_global();
   const int wpb = (SPEC == 1 || SPEC == 2) ? WAVES_PER_BLOCK : (int)(blockDim.x / WAVE);
@@ -1791,7 +1829,7 @@ __device__ __attribute__((noinline)) void ph_gaze_stages(const ClosedArgs *ap, i
   load_regs(a->s, e, r);
   // this step's row of the measurement noise (d2d_cfg.noise_rows; utils.py:605 draws fresh normals every step)
   const size_t noise_off = c.noise_rows > 1 ? (size_t)((c.noise_row0 + tstep) % c.noise_rows) * c.B * c.N * 2 : 0;
-  run_env<spec_full(SPEC), spec_wide(SPEC), spec_cone(SPEC)>(c, a->s, e, lane, STAGES, g, L, a->s.action[e], r, noise_off);
+  run_env<spec_full(SPEC), spec_wide(SPEC), spec_cone(SPEC), spec_tiled(SPEC)>(c, a->s, e, lane, STAGES, g, L, a->s.action[e], r, noise_off);
   if (lane == 0) store_regs(a->s, e, r);
   wave_sync_global();
 }
@@ -1802,13 +1840,13 @@ __device__ __attribute__((noinline)) void ph_stages(const ClosedArgs *ap, int e_
   const int e = __builtin_amdgcn_readfirstlane(e_), lane = threadIdx.x & (WAVE - 1);
   char *base = d2d_lds + __builtin_amdgcn_readfirstlane(lds_off_);
   d2d_cfg c = a->c;
-  if (SPEC != 0) spec_default_apply(c);
+  if (!spec_generic(SPEC)) spec_default_apply(c);
   const int wpb = (SPEC == 1 || SPEC == 2) ? WAVES_PER_BLOCK : (int)(blockDim.x / WAVE);
   const Geom g = make_geom(c, wpb, spec_ncap(SPEC), spec_full(SPEC));
   const LdsView L = carve(base, g, c.L);
   EnvRegs r;
   load_regs(a->s, e, r);
-  run_env<spec_full(SPEC), spec_wide(SPEC), spec_cone(SPEC)>(c, a->s, e, lane, STAGES, g, L, a->s.action[e], r);
+  run_env<spec_full(SPEC), spec_wide(SPEC), spec_cone(SPEC), spec_tiled(SPEC)>(c, a->s, e, lane, STAGES, g, L, a->s.action[e], r);
   if (lane == 0) store_regs(a->s, e, r);
   wave_sync_global();
 }
@@ -1820,7 +1858,7 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK, D2D_MIN_WAVES) void k_closed
   const int e = blockIdx.x * wpb + wv;
   if (e >= a->c.B) return;
   d2d_cfg c = a->c;
-  if (SPEC != 0) spec_default_apply(c);
+  if (!spec_generic(SPEC)) spec_default_apply(c);
   const int off = wv * closed_wave_bytes<SPEC>(c, a->p, wpb);
   const bool split = a->p.planner == D2D_PLAN_PRIMITIVE;
   const int nsteps = a->nsteps;
@@ -1927,6 +1965,7 @@ int check(const d2d_cfg *c, const d2d_state *s) {
   if (c->B < 0 || c->N < 0 || c->W <= 0 || c->H <= 0 || c->R <= 0 || c->L <= 0 || (c->L & 1) == 0 || c->T <= 0)
     return fail(-1, "bad dimensions");
   if (c->noise_row0 < 0 || c->noise_row0 >= (c->noise_rows > 1 ? c->noise_rows : 1)) return fail(-1, "noise_row0 outside [0, noise_rows)");
+  if (c->grid_tile != 0 && c->grid_tile != 16) return fail(-1, "grid_tile must be 0 (row-major [W][H]) or 16 (16 x 16-cell tiles)");
   if (c->W > 32767 || c->H > 32767) return fail(-4, "grids of more than 32767 cells a side are not supported (16-bit cell planes in LDS)");
   if (!(c->scale >= 2.0) || c->scale != (double)(long long)c->scale)
     return fail(-4, "map_scale must be an integer >= 2 (scale 1 never advances a ray, utils.py:621)");
@@ -1974,8 +2013,13 @@ int launch_stages(const d2d_cfg *c, const d2d_state *s, uint32_t stages, void *s
     const int wpb = pick_wpb(*c);
     const Geom g = make_geom(*c, wpb);
     const dim3 grid((c->B + wpb - 1) / wpb), block(WAVE * wpb);
-    lds_optin(k_stages<0>, (size_t)g.wave_bytes * wpb);
-    hipLaunchKernelGGL(k_stages<0>, grid, block, (size_t)g.wave_bytes * wpb, (hipStream_t)stream, ka);
+    if (c->grid_tile) {
+      lds_optin(k_stages<4>, (size_t)g.wave_bytes * wpb);
+      hipLaunchKernelGGL(k_stages<4>, grid, block, (size_t)g.wave_bytes * wpb, (hipStream_t)stream, ka);
+    } else {
+      lds_optin(k_stages<0>, (size_t)g.wave_bytes * wpb);
+      hipLaunchKernelGGL(k_stages<0>, grid, block, (size_t)g.wave_bytes * wpb, (hipStream_t)stream, ka);
+    }
   }
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return fail(-3, hipGetErrorString(err));
@@ -2168,10 +2212,13 @@ int d2d_closed_loop(const d2d_cfg *c, const d2d_state *s, const d2d_plan *p, int
       ClosedArgs *dev = (ClosedArgs *)p->launch_args;
       hipLaunchKernelGGL(k_closed_args, dim3(1), dim3(64), 0, (hipStream_t)stream, dev, *c, *s, *p, auto_reset ? *init : *s,
                          (int)on_done, (int)nsteps);
-      if (spec == 0) lds_optin(k_closed<0>, lds);
+      if (spec == 0) lds_optin(k_closed<0>, lds), lds_optin(k_closed<4>, lds);
       if (spec == 3) lds_optin(k_closed<3>, lds);
       switch (spec) {
-        case 0: hipLaunchKernelGGL(k_closed<0>, grid, block, lds, (hipStream_t)stream, (const ClosedArgs *)dev); break;
+        case 0:
+          if (c->grid_tile) hipLaunchKernelGGL(k_closed<4>, grid, block, lds, (hipStream_t)stream, (const ClosedArgs *)dev);
+          else hipLaunchKernelGGL(k_closed<0>, grid, block, lds, (hipStream_t)stream, (const ClosedArgs *)dev);
+          break;
         case 1: hipLaunchKernelGGL(k_closed<1>, grid, block, lds, (hipStream_t)stream, (const ClosedArgs *)dev); break;
         case 2: hipLaunchKernelGGL(k_closed<2>, grid, block, lds, (hipStream_t)stream, (const ClosedArgs *)dev); break;
         default: hipLaunchKernelGGL(k_closed<3>, grid, block, lds, (hipStream_t)stream, (const ClosedArgs *)dev); break;

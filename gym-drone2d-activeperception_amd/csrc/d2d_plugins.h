@@ -143,8 +143,8 @@ __device__ __forceinline__ bool plan_is_free(const d2d_cfg &c, const d2d_plan &p
             i2 = min(max(cell_fast(xr, c.scale, inv_scale), 0), W1);
   const int j0 = min(max(cell_fast(yl, c.scale, inv_scale), 0), H1), j1 = min(max(cell_fast(y, c.scale, inv_scale), 0), H1),
             j2 = min(max(cell_fast(yr, c.scale, inv_scale), 0), H1);
-  const unsigned char v0 = dm[i0 * c.H + j1], v1 = dm[i1 * c.H + j1], v2 = dm[i2 * c.H + j1], v3 = dm[i1 * c.H + j0],
-                      v4 = dm[i1 * c.H + j2];
+  const unsigned char v0 = dm[grid_ix(c, i0, j1)], v1 = dm[grid_ix(c, i1, j1)], v2 = dm[grid_ix(c, i2, j1)], v3 = dm[grid_ix(c, i1, j0)],
+                      v4 = dm[grid_ix(c, i1, j2)];
   // out of the map = wall (get_grid): x >= W_px or x < 0 or y >= H_px or y < 0, per probe
   const bool ox0 = (xl >= c.W_px) | (xl < 0.0), ox1 = (x >= c.W_px) | (x < 0.0), ox2 = (xr >= c.W_px) | (xr < 0.0);
   const bool oy0 = (yl >= c.H_px) | (yl < 0.0), oy1 = (y >= c.H_px) | (y < 0.0), oy2 = (yr >= c.H_px) | (yr < 0.0);
@@ -169,8 +169,8 @@ __device__ __forceinline__ bool plan_wall_int(const d2d_cfg &c, DM dm, int xi, i
   const int i0 = min(D2D_BY10(xl, Wm), W1), i1 = min(D2D_BY10(xi, Wm), W1), i2 = min(D2D_BY10(xr, Wm), W1);
   const int j0 = min(D2D_BY10(yl, Hm), H1), j1 = min(D2D_BY10(yi, Hm), H1), j2 = min(D2D_BY10(yr, Hm), H1);
 #undef D2D_BY10
-  const unsigned char v0 = dm[i0 * c.H + j1], v1 = dm[i1 * c.H + j1], v2 = dm[i2 * c.H + j1], v3 = dm[i1 * c.H + j0],
-                      v4 = dm[i1 * c.H + j2];
+  const unsigned char v0 = dm[grid_ix(c, i0, j1)], v1 = dm[grid_ix(c, i1, j1)], v2 = dm[grid_ix(c, i2, j1)], v3 = dm[grid_ix(c, i1, j0)],
+                      v4 = dm[grid_ix(c, i1, j2)];
   return (ox0 | oy1 | (v0 == D2D_OCCUPIED)) | (ox1 | oy1 | (v1 == D2D_OCCUPIED)) | (ox2 | oy1 | (v2 == D2D_OCCUPIED)) |
          (ox1 | oy0 | (v3 == D2D_OCCUPIED)) | (ox1 | oy2 | (v4 == D2D_OCCUPIED));
 }
@@ -320,7 +320,7 @@ __device__ int plan_search(const d2d_cfg &c, const d2d_state &s, const d2d_plan 
     for (int i0 = 0; i0 < c.W; i0 += 8) {
       unsigned char v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = dm[min(i0 + u, c.W - 1) * c.H + jc];
+      for (int u = 0; u < 8; ++u) v[u] = dm[grid_ix(c, min(i0 + u, c.W - 1), jc)];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         if (i0 + u < c.W) {  // wave-uniform
@@ -365,12 +365,37 @@ __device__ int plan_search(const d2d_cfg &c, const d2d_state &s, const d2d_plan 
   wave_sync_global();
   SP_T(spb);
   SP_ADD(10, spa, spb);
+  // Two successors of ONE node differ in x_acc or y_acc, hence by 2 H |delta acc| / 2 >= H * (spacing of u_space) in an end velocity,
+  // hence -- once that exceeds 1 (+ slack for the roundings) -- in round(v): their dict keys differ, and the successors of an
+  // expansion need no de-duplication among themselves.  (u_space = arange(-a, a, 0.4 vmax - 5) or step 4: always, for drone speeds
+  // of 14 and more.)
+  bool nodup;
+  {
+    double dmin = 1e300;
+    for (int i = lane; i + 1 < p.nu; i += WAVE) dmin = fmin(dmin, p.u_space[i + 1] - p.u_space[i]);
+    for (int o = 32; o > 0; o >>= 1) dmin = fmin(dmin, shfl_f64(dmin, (lane ^ o)));
+    nodup = H * dmin > 1.0 + 1e-6;
+  }
   int nn = 1, open_n = 1, goal = -1, itr = 0, expansions = 0;
   bool overflow = false;
   bool lds_dict = true;  // the dict lives in LDS (S.lh); false once the search has outgrown it: then in `tab`
   const int nprim = p.nu * p.nu;
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
   const FastDiv fd_nu(p.nu), fd_ns(p.n_sample);
+  // |sample| <= |p| + T |v| + T^2 |a| / 2 for every sample time T < horizon: one bound per expansion instead of a test per sample
+  double amax = 0.0;
+  for (int i = 0; i < p.nu; ++i) amax = fmax(amax, fabs(p.u_space[i]));
+  const double reach_a = 0.5 * H * H * amax + 2.0;
+  // the pairs of one primitive never straddle two rounds of 64 when n_sample divides 64: its free samples are one bit field
+  const bool ns_pow2 = (p.n_sample & (p.n_sample - 1)) == 0 && p.n_sample <= WAVE;
+  const bool one_batch = false;  // (the lane's accelerations kept in registers across the search: measured, no gain -- they spill)
+  double ax1 = 0.0, ay1 = 0.0;
+  if (one_batch) {
+    int ia, ja;
+    fd_nu.divmod(lane < nprim ? lane : 0, ia, ja);
+    ax1 = S.us[ia];
+    ay1 = S.us[ja];
+  }
   for (;;) {
     itr += 1;
     if (open_n == 0 || itr >= p.max_itr) break;
@@ -433,6 +458,8 @@ __device__ int plan_search(const d2d_cfg &c, const d2d_state &s, const d2d_plan 
     const double ccost = rc[NR_COST];
     const int citr = meta_itr(rc[NR_META]);
     const double px = cpos.x, py = cpos.y, vx = cvel.x, vy = cvel.y;
+    // every collision sample of this expansion fits an int (also false for NaN / infinite state)
+    const bool fits_all = int_walls && (fabs(px) + H * fabs(vx) + reach_a <= 4194304.0) && (fabs(py) + H * fabs(vy) + reach_a <= 4194304.0);
     SP_T(sp2);
     SP_ADD(1, sp1, sp2);
     if (__builtin_fma(py - ty, py - ty, (px - tx) * (px - tx)) <= goal2) {  // :158
@@ -449,9 +476,16 @@ __device__ int plan_search(const d2d_cfg &c, const d2d_state &s, const d2d_plan 
     for (int p0 = 0; p0 < nprim && !overflow; p0 += WAVE) {
       const int pi = p0 + lane;
       bool ok = pi < nprim;
-      int ia, ja;
-      fd_nu.divmod(ok ? pi : 0, ia, ja);  // no integer divisions in the loop: ~25 instructions each
-      const double ax = S.us[ia], ay = S.us[ja];
+      double ax, ay;
+      if (one_batch) {  // the lane's primitive never changes: its accelerations stay in registers
+        ax = ax1;
+        ay = ay1;
+      } else {
+        int ia, ja;
+        fd_nu.divmod(ok ? pi : 0, ia, ja);  // no integer divisions in the loop: ~25 instructions each
+        ax = S.us[ia];
+        ay = S.us[ja];
+      }
       const double hx = ax / 2, hy = ay / 2;
       const double vex = vx + (2 * H) * hx, vey = vy + (2 * H) * hy;  // :172,183
       ok = ok && (__builtin_fma(vey, vey, vex * vex) <= vmax2);
@@ -478,7 +512,7 @@ __device__ int plan_search(const d2d_cfg &c, const d2d_state &s, const d2d_plan 
         // ballots: every primitive counts the set bits of its own pairs -- no LDS counters, no hand-off
         for (int q0 = 0; q0 < npair; q0 += 2 * WAVE) {
           int pr[2], si[2];
-          bool in[2], fr[2], fits[2];
+          bool in[2], fr[2];
           double sxv[2], syv[2], tgv[2];
 #pragma unroll
           for (int u = 0; u < 2; ++u) {
@@ -496,23 +530,27 @@ __device__ int plan_search(const d2d_cfg &c, const d2d_state &s, const d2d_plan 
             const double sx = rint(__builtin_fma(tt2[u], shx[u], px + tt[u] * vx)), sy = rint(__builtin_fma(tt2[u], shy[u], py + tt[u] * vy));
             const double tg = tt[u] + (double)citr * H;
             sxv[u] = sx; syv[u] = sy; tgv[u] = tg;
-            fits[u] = fabs(sx) <= 4194304.0 && fabs(sy) <= 4194304.0;  // also false for NaN
           }
-          if (int_walls && __all((int)fits[0] & (int)fits[1])) {  // wave-uniform: integer probes
+          if (fits_all) {  // wave-uniform: integer probes
+            // walls and trackers of both rounds without a branch between them (`&`, not `&&`): a short-circuit costs an exec-mask
+            // branch per round and keeps the second round's loads from overlapping the first one's arithmetic
+            bool wall[2];
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
               const int xi = (int)sxv[u], yi = (int)syv[u];
-              bool wall;
               if (rows) {
+                // outside the map = wall whatever the row says: only the row index has to stay inside the table
                 const bool inside = ((unsigned int)xi < (unsigned int)wpx_i) & ((unsigned int)yi < (unsigned int)hpx_i);
-                const int ci = (int)(__umul24((unsigned int)min(max(xi, 0), wpx_i - 1), 52429u) >> 19);
-                const int cj = (int)(__umul24((unsigned int)min(max(yi, 0), hpx_i - 1), 52429u) >> 19);
-                wall = !inside | (((S.prow[ci] >> cj) & 1ull) != 0ull);
+                unsigned int ci = __umul24((unsigned int)xi, 52429u) >> 19;
+                ci = ci < 63u ? ci : 63u;
+                const unsigned int cj = (__umul24((unsigned int)yi, 52429u) >> 19) & 63u;
+                wall[u] = !inside | (((S.prow[ci] >> cj) & 1ull) != 0ull);
               } else {
-                wall = plan_wall_int(c, dm, xi, yi, safe_i, wpx_i, hpx_i);
+                wall[u] = plan_wall_int(c, dm, xi, yi, safe_i, wpx_i, hpx_i);
               }
-              fr[u] = !wall && !plan_hits_tracker(T, sxv[u], syv[u], tgv[u]);
             }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) fr[u] = !wall[u] & !plan_hits_tracker(T, sxv[u], syv[u], tgv[u]);
           } else {
 #pragma unroll
             for (int u = 0; u < 2; ++u) fr[u] = plan_is_free(c, p, dm, T, sxv[u], syv[u], tgv[u], inv_scale);
@@ -521,10 +559,15 @@ __device__ int plan_search(const d2d_cfg &c, const d2d_state &s, const d2d_plan 
           for (int u = 0; u < 2; ++u) {
             const unsigned long long fm = __ballot(in[u] & fr[u]);
             const int qb = q0 + u * WAVE;  // this round holds the pairs [qb, qb + 64)
-            const int lo = max(my_lo, qb) - qb, hi = min(my_lo + p.n_sample, qb + WAVE) - qb;
-            if (hi > lo) {
-              const unsigned long long w = fm >> lo;
-              nfree += __popcll(hi - lo >= WAVE ? w : (w & ((1ull << (hi - lo)) - 1ull)));
+            if (ns_pow2) {
+              const unsigned int sh = (unsigned int)(my_lo - qb);
+              if (sh < (unsigned int)WAVE) nfree = __popcll(p.n_sample >= WAVE ? fm : ((fm >> sh) & ((1ull << p.n_sample) - 1ull)));
+            } else {
+              const int lo = max(my_lo, qb) - qb, hi = min(my_lo + p.n_sample, qb + WAVE) - qb;
+              if (hi > lo) {
+                const unsigned long long w = fm >> lo;
+                nfree += __popcll(hi - lo >= WAVE ? w : (w & ((1ull << (hi - lo)) - 1ull)));
+              }
             }
           }
         }
@@ -592,7 +635,7 @@ __device__ int plan_search(const d2d_cfg &c, const d2d_state &s, const d2d_plan 
       const unsigned long long m = __ballot(ok);
       const int nok = __popcll(m), rank = __popcll(m & lt_mask);
       unsigned long long dupm = 0;
-      {
+      if (!nodup) {
         unsigned long long *bk = (unsigned long long *)chain;
         bk[lane] = 0ull;  // LDS operations of one wave execute in order: the swaps below see the cleared table
         const unsigned long long ukey = (unsigned long long)key;
@@ -633,7 +676,7 @@ __device__ int plan_search(const d2d_cfg &c, const d2d_state &s, const d2d_plan 
           wlane = better ? lj : wlane;
         }
       }
-      wave_sync_lds();
+      if (!nodup) wave_sync_lds();
       SP_T(sp6);
       SP_ADD(5, sp5, sp6);
       const bool is_leader = ok && leader == lane;
@@ -648,7 +691,7 @@ __device__ int plan_search(const d2d_cfg &c, const d2d_state &s, const d2d_plan 
       }
       int myslot = slot;
       if (is_leader && !exists) myslot = nn + __popcll(newm & lt_mask);
-      const int gslot = __shfl(myslot, leader, WAVE);  // the slot of my group
+      const int gslot = dupm != 0ull ? __shfl(myslot, leader, WAVE) : myslot;  // the slot of my group (no repeats: my own)
       const bool write = ok && wlane == lane && (!exists || (!closed && ecost > wcost));
       if (write) {
         double *rw = nd.rec(gslot);
@@ -838,7 +881,7 @@ __device__ __forceinline__ bool plan_env_quick(const d2d_cfg &c, const d2d_state
   SearchLds S;
   plan_carve(c, p, base, T, S);
   const double inv_scale = 1.0 / c.scale;
-  const unsigned char *__restrict__ dm = s.dmap + (size_t)e * c.W * c.H;
+  const unsigned char *__restrict__ dm = s.dmap + (size_t)e * grid_bytes(c);
   // ---- trackers: archive bookkeeping (utils.py:184,238) and the active ones into LDS ----
   int nact = 0;
   for (int k0 = 0; k0 < N; k0 += WAVE) {
@@ -892,7 +935,7 @@ __device__ __forceinline__ bool plan_env_quick(const d2d_cfg &c, const d2d_state
         const bool in = ci >= 0 && ci < c.W && cj >= 0 && cj < c.H;
         // swep_map is uint8: the stored value is trunc(i * dt); a wall under a non-zero stored value forces the replan
         const int sv = ((int)ti) & 0xff;
-        if (in && sv > 0 && dm[min(max(ci, 0), c.W - 1) * c.H + min(max(cj, 0), c.H - 1)] == D2D_OCCUPIED) bad = true;
+        if (in && sv > 0 && dm[grid_ix(c, min(max(ci, 0), c.W - 1), min(max(cj, 0), c.H - 1))] == D2D_OCCUPIED) bad = true;
         for (int q = 0; q < nact; q += 4) {  // four trackers per round, loads first (see plan_is_free)
           double mx[4], my[4], vx[4], vy[4], lim[4];
 #pragma unroll
@@ -940,7 +983,7 @@ __device__ __forceinline__ void plan_env_search(const d2d_cfg &c, const d2d_stat
   plan_carve(c, p, base, T, S);
   T.n = S.misc[0];  // the trackers are still in LDS, the limit plane holds plan's thresholds (plan_env_quick)
   const double inv_scale = 1.0 / c.scale;
-  const unsigned char *__restrict__ dm = s.dmap + (size_t)e * c.W * c.H;
+  const unsigned char *__restrict__ dm = s.dmap + (size_t)e * grid_bytes(c);
   // A search is a long chain of short dependent steps and, in the persistent loop, what the slowest env of a launch
   // spends its time on; its wave shares the SIMD with three others that mostly run throughput phases.  Raised issue
   // priority lets it go first whenever it is ready (0.78 ms -> its stand-alone 0.46 ms is the range at stake).

@@ -240,7 +240,7 @@ class Drone2DEnv2(_EnvBase):
         self._mode = ('fused' if p.planner == 'NoMove' else 'device') if on_device else 'host'
         want_gaze = on_device and p.gaze_method == 'Oxford'
         plugins = self._mode == 'device' or want_gaze
-        self._vec = VecDrone2DEnv(p, 1, device=self._device, backend=self._backend,
+        self._vec = VecDrone2DEnv(p, 1, device=self._device, backend=self._backend, grid_layout='rowmajor',   # the proxies index [W][H]
                                   planner=p.planner if on_device else 'external', device_plugins=plugins,
                                   gaze=('Oxford' if want_gaze else 'external') if plugins else None)
         self._slot = 0

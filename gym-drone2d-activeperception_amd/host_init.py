@@ -164,7 +164,7 @@ def init_world(params):
                 tracker_radius=tracker_radius, N=N, W=W, H=H, T=T)
 
 
-def derive_cfg(params, B, N, T=1, planner_mode=A.PLANNER_EXTERNAL, kf_enabled=True):
+def derive_cfg(params, B, N, T=1, planner_mode=A.PLANNER_EXTERNAL, kf_enabled=True, grid_tile=0):
     """Numeric constants of one batch (include/d2d.h d2d_cfg), evaluated exactly as the reference's
     Python evaluates them."""
     p = params
@@ -176,6 +176,7 @@ def derive_cfg(params, B, N, T=1, planner_mode=A.PLANNER_EXTERNAL, kf_enabled=Tr
     c.L = 4 * (p.drone_view_depth // p.map_scale) + 1         # drone_v2.py:133
     c.planner_mode = planner_mode
     c.kf_enabled = 1 if kf_enabled else 0
+    c.grid_tile = int(grid_tile)
     fov = math.radians(p.drone_view_range)                    # utils.py:575
     c.dt, c.scale = p.dt, p.map_scale
     c.W_px, c.H_px = p.map_size[0], p.map_size[1]

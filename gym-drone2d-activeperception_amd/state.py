@@ -10,11 +10,39 @@ import torch
 from . import _abi as A
 
 
-def _spec(B, N, W, H, L, T):
+TILE = 16          # d2d_cfg.grid_tile: cells per tile edge of the tiled grid layout (include/d2d.h)
+
+
+def tile_grid(g, tile=TILE):
+    """[..., W, H] row-major grid(s) -> [..., ceil(W / 16) * ceil(H / 16) * 256] in the tiled layout of include/d2d.h
+    (d2d_cfg.grid_tile = 16): tiles row-major over (ceil(W / 16), ceil(H / 16)), cells row-major inside a tile; cells of the
+    padding (W or H not a multiple of 16) are 0 and never read."""
+    g = torch.as_tensor(g)
+    W, H = g.shape[-2:]
+    Wt, Ht = -(-W // tile), -(-H // tile)
+    lead = g.shape[:-2]
+    if (Wt * tile, Ht * tile) != (W, H):
+        pad = torch.zeros(lead + (Wt * tile, Ht * tile), dtype=g.dtype, device=g.device)
+        pad[..., :W, :H] = g
+        g = pad
+    g = g.reshape(lead + (Wt, tile, Ht, tile)).transpose(-3, -2)
+    return g.reshape(lead + (Wt * Ht * tile * tile,)).contiguous()
+
+
+def untile_grid(t, W, H, tile=TILE):
+    """Inverse of tile_grid: [..., Wt * Ht * 256] -> [..., W, H] (a copy)."""
+    Wt, Ht = -(-W // tile), -(-H // tile)
+    lead = t.shape[:-1]
+    g = t.reshape(lead + (Wt, Ht, tile, tile)).transpose(-3, -2).reshape(lead + (Wt * tile, Ht * tile))
+    return g[..., :W, :H].contiguous()
+
+
+def _spec(B, N, W, H, L, T, grid_tile=0):
     f64, i32, u8, f32 = torch.float64, torch.int32, torch.uint8, torch.float32
+    gshape = (B, (-(-W // grid_tile)) * (-(-H // grid_tile)) * grid_tile * grid_tile) if grid_tile else (B, W, H)
     return dict(
         agents=((B, A.AF, N), f64), agent_unit=((B, N), i32), dyn_prev=((B, N, 3), i32),
-        gt=((B, W, H), u8), dmap=((B, W, H), u8), drone=((B, A.DF), f64), target=((B, 2), f64),
+        gt=(gshape, u8), dmap=(gshape, u8), drone=((B, A.DF), f64), target=((B, 2), f64),
         targets=((B, T, 2), f64), counters=((B, A.CF), i32), active=((B, N), u8),
         kf=((B, N, A.KF), f64), kf_len=((B, N), i32),
         action=((B,), f64), plan_ok=((B,), u8), wp_valid=((B,), u8), wp=((B, 6), f64),
@@ -33,7 +61,7 @@ class BatchState:
         self.cfg = cfg
         self.device = torch.device(device)
         self.t = {}
-        for name, (shape, dt) in _spec(cfg.B, cfg.N, cfg.W, cfg.H, cfg.L, cfg.T).items():
+        for name, (shape, dt) in _spec(cfg.B, cfg.N, cfg.W, cfg.H, cfg.L, cfg.T, cfg.grid_tile).items():
             self.t[name] = torch.zeros(shape, dtype=dt, device=self.device)
         self.noise = None
         self._dummy = torch.zeros(64, dtype=torch.float64, device=self.device)   # target of empty fields (N == 0)
@@ -52,6 +80,21 @@ class BatchState:
             return t[name]
         raise AttributeError(name)
 
+    def logical(self, name):
+        """Field `name` as the reference indexes it: the grids come back [B, W, H] whatever the device layout (a de-tiled copy
+        when cfg.grid_tile != 0 -- write through `set_grid`), every other field is the tensor itself."""
+        t = self.t[name]
+        if name in ('gt', 'dmap') and self.cfg.grid_tile:
+            return untile_grid(t, self.cfg.W, self.cfg.H, self.cfg.grid_tile)
+        return t
+
+    def set_grid(self, name, grid, envs=slice(None)):
+        """Overwrite grid `name` ('gt' / 'dmap') of `envs` from [n, W, H] values given in the reference's indexing."""
+        g = torch.as_tensor(grid, dtype=torch.uint8)
+        if self.cfg.grid_tile:
+            g = tile_grid(g, self.cfg.grid_tile)
+        self.t[name][envs] = g.to(self.device)
+
     def load_worlds(self, worlds):
         """Fill the world fields from a list of host_init.init_world() dicts (one per env)."""
         B = self.cfg.B
@@ -61,8 +104,10 @@ class BatchState:
             per = max(1, int(np.asarray(worlds[0][name]).nbytes))
             step = max(1, (256 << 20) // per)
             for c0 in range(0, B, step):
-                arr = np.stack([w[name] for w in worlds[c0:c0 + step]])
-                self.t[name][c0:c0 + step].copy_(torch.from_numpy(arr).to(self.t[name].dtype))
+                arr = torch.from_numpy(np.stack([w[name] for w in worlds[c0:c0 + step]])).to(self.t[name].dtype)
+                if name in ('gt', 'dmap') and self.cfg.grid_tile:
+                    arr = tile_grid(arr, self.cfg.grid_tile)
+                self.t[name][c0:c0 + step].copy_(arr)
         self.t['active'].zero_()
         self._kf_defaults()
 

@@ -44,7 +44,7 @@ def build_worlds(params, num_envs, env_offset=0, workers=0):
 
 class VecDrone2DEnv:
     def __init__(self, params, num_envs, device='cuda:0', planner=None, env_offset=0, backend=None,
-                 kf_enabled=True, worlds=None, device_plugins=False, gaze=None):
+                 kf_enabled=True, worlds=None, device_plugins=False, gaze=None, grid_layout=None):
         self.params = with_defaults(params)
         self.num_envs = int(num_envs)
         self.env_offset = int(env_offset)
@@ -61,8 +61,17 @@ class VecDrone2DEnv:
         T = worlds[0]['T'] if worlds else 1
         if any(w['N'] != N for w in worlds):
             raise ValueError('all envs of a batch must have the same number of agents')
-        self.cfg = host_init.derive_cfg(self.params, B=self.num_envs, N=N, T=T,
-                                        planner_mode=self.planner_mode, kf_enabled=kf_enabled)
+        # device layout of the two grids (include/d2d.h d2d_cfg.grid_tile): 'rowmajor' = the reference's [W][H]; 'tiled' = 16 x 16-cell
+        # tiles.  Default: tiled on the HIP backend for grids above 256 x 256 cells (BASELINE config 5: a 3 x 3 block or a 23-byte
+        # window row of a 640-cell row-major grid costs a cache line each), row-major otherwise; `state.logical()` / the facade
+        # proxies always speak [W][H].
+        W, H = self.params.map_size[0] // self.params.map_scale, self.params.map_size[1] // self.params.map_scale
+        if grid_layout is None:
+            grid_layout = 'tiled' if (W * H > 256 * 256 and getattr(backend, 'supports_tiled_grids', False)) else 'rowmajor'
+        if grid_layout not in ('rowmajor', 'tiled'):
+            raise ValueError(f'grid_layout {grid_layout!r}: rowmajor or tiled')
+        self.cfg = host_init.derive_cfg(self.params, B=self.num_envs, N=N, T=T, planner_mode=self.planner_mode,
+                                        kf_enabled=kf_enabled, grid_tile=16 if grid_layout == 'tiled' else 0)
         self.state = BatchState(self.cfg, self.device)
         self.state.load_worlds(worlds)
         self.tracker_radius = torch.from_numpy(np.stack([w['tracker_radius'] for w in worlds])) if worlds else None

@@ -137,6 +137,14 @@ typedef struct d2d_cfg {
                           (utils.py:605); 0 or 1 = one row used by every step (single-step entry points always use row 0) */
   int32_t noise_row0;  /* the row the FIRST step of a multi-step call draws from (ABI 7): a caller that cuts a run into several
                           calls advances it by the steps of each call, so that the pieces draw the rows the whole run would */
+  int32_t grid_tile;   /* layout of `gt` and `dmap` inside one env (ABI 7).  0: row-major [W][H], the reference's indexing
+                          (utils.py:548) and the default.  16: 16 x 16-cell tiles of 256 contiguous bytes, tiles row-major over
+                          (ceil(W / 16), ceil(H / 16)), cells row-major inside a tile -- cell (i, j) at byte
+                          ((i / 16) * ceil(H / 16) + j / 16) * 256 + (i % 16) * 16 + j % 16; every env then takes
+                          ceil(W / 16) * ceil(H / 16) * 256 bytes per grid (D2D_GRID_BYTES).  For grids of hundreds of cells a side,
+                          where a 3 x 3 block or a 23-byte window row of the row-major layout costs a cache line of its own; the host
+                          converts at the boundary (state.py tile_grid / untile_grid).  liboracle takes 0 only. */
+  int32_t reserved2;
   double dt;           /* params.dt */
   double scale;        /* params.map_scale (x_scale == y_scale, utils.py:500-501) */
   double W_px, H_px;   /* params.map_size */
@@ -151,14 +159,17 @@ typedef struct d2d_cfg {
   double kf_lo_x, kf_hi_x, kf_lo_y, kf_hi_y; /* 10 + agent_radius, map_size - 10 - agent_radius (utils.py:236-237) */
 } d2d_cfg;
 
+/* bytes of one env's `gt` (or `dmap`) under cfg->grid_tile */
+#define D2D_GRID_BYTES(cfg) ((cfg)->grid_tile ? (size_t)(((cfg)->W + 15) / 16) * (size_t)(((cfg)->H + 15) / 16) * 256 : (size_t)(cfg)->W * (size_t)(cfg)->H)
+
 typedef struct d2d_state {
   /* ---- world state (read + written) ---- */
   double D2D_AS *agents;      /* [B][D2D_AF][N] */
   int32_t D2D_AS *agent_unit; /* [B][N]  int(radius // scale) (utils.py:533-534) */
   int32_t D2D_AS *dyn_prev;   /* [B][N][3] cell block (cx, cy, half) that may hold DYNAMIC cells written for
                           this agent last time: replaces the dynamic_idx list (utils.py:506,528-530) */
-  uint8_t D2D_AS *gt;         /* [B][W][H] ground-truth grid, env.map_gt.grid_map */
-  uint8_t D2D_AS *dmap;       /* [B][W][H] the drone's explored map, env.drone.map.grid_map */
+  uint8_t D2D_AS *gt;         /* [B][W][H] ground-truth grid, env.map_gt.grid_map ([B][D2D_GRID_BYTES] when cfg.grid_tile != 0) */
+  uint8_t D2D_AS *dmap;       /* [B][W][H] the drone's explored map, env.drone.map.grid_map (same layout as gt) */
   double D2D_AS *drone;       /* [B][D2D_DF] */
   double D2D_AS *target;      /* [B][2] planner.target[:2] */
   double D2D_AS *targets;     /* [B][T][2] env.target_list */

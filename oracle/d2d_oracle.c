@@ -477,6 +477,7 @@ static int check(const d2d_cfg *c, const d2d_state *s) {
   if (c->B < 0 || c->N < 0 || c->W <= 0 || c->H <= 0 || c->R <= 0 || c->L <= 0 || (c->L & 1) == 0)
     return fail(-1, "bad dimensions");
   if (c->noise_row0 < 0 || c->noise_row0 >= (c->noise_rows > 1 ? c->noise_rows : 1)) return fail(-1, "noise_row0 outside [0, noise_rows)");
+  if (c->grid_tile != 0) return fail(-4, "the oracle keeps the reference's row-major grids (grid_tile must be 0)");
   if (!(c->scale >= 2)) return fail(-4, "map_scale < 2: the reference's ray march never advances (utils.py:621)");
   if (c->kf_enabled && (!s->kf || !s->kf_len)) return fail(-1, "kf_enabled without kf buffers");
   if (c->planner_mode == D2D_PLANNER_EXTERNAL && (!s->plan_ok || !s->wp_valid || !s->wp))

@@ -35,7 +35,7 @@ def test_header_constants_match_ctypes_mirror(pkg):
         if m:
             names += [n.strip() for n in m.group(2).split(',')]
     assert names == [f[0] for f in A.Cfg._fields_]
-    assert C.sizeof(A.Cfg) == 12 * 4 + 16 * 8 and C.sizeof(A.State) == len(A.STATE_FIELDS) * 8
+    assert C.sizeof(A.Cfg) == 14 * 4 + 16 * 8 and C.sizeof(A.State) == len(A.STATE_FIELDS) * 8
     # d2d_plan: scalars in declaration order, then the pointers
     body = HDR[HDR.index('typedef struct d2d_plan {'):HDR.index('} d2d_plan;')]
     names = []

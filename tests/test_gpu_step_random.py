@@ -84,10 +84,18 @@ N_LARGE = max(6, N_SEEDS // 5)
 @pytest.mark.parametrize('family,seed', [('any', s) for s in list(range(SEED_BASE, SEED_BASE + N_SEEDS)) +
                                          (REGRESSION_SEEDS if SEED_BASE == 0 else [])] +
                          [('default', s) for s in range(SEED_BASE, SEED_BASE + N_SEEDS)] +
-                         [('large', s) for s in range(SEED_BASE, SEED_BASE + N_LARGE)])
+                         [('large', s) for s in range(SEED_BASE, SEED_BASE + N_LARGE)] +
+                         [('large-rowmajor', s) for s in range(SEED_BASE, SEED_BASE + N_LARGE)] +
+                         [('any-tiled', s) for s in range(SEED_BASE, SEED_BASE + N_LARGE)])
 def test_random_step_matches_oracle(pkg, hip, oracle, family, seed):
+    # 'large' runs in the library's default layout for such grids (16 x 16-cell tiles, d2d_cfg.grid_tile), 'large-rowmajor' the same
+    # configurations in the reference's [W][H]; 'any-tiled' puts grids of every size and scale into tiles (W, H not multiples of 16)
+    layout = {'large-rowmajor': 'rowmajor', 'any-tiled': 'tiled'}.get(family)
+    family = family.split('-')[0]
     rng = np.random.RandomState({'any': 7000, 'default': 57000, 'large': 107000}[family] + seed)
     kw = {'any': _cfg, 'default': _cfg_default_geometry, 'large': _cfg_large_grid}[family](rng)
+    if layout:
+        kw['grid_layout'] = layout
     B, T = int(rng.choice([2, 5, 9])), 24
     if family == 'large':
         B, T = int(rng.choice([2, 3])), 10
@@ -137,6 +145,8 @@ def test_random_step_matches_oracle(pkg, hip, oracle, family, seed):
                 dev.backend.run_stages(dev.cfg, dev._st, 1 << b)
         ref.step(a)
         _assert_same(dev, ref, f'{family} seed {seed} {kw} external={external} mode={mode} step {t + 1}')
+    if family == 'large':
+        assert dev.cfg.grid_tile == (0 if layout == 'rowmajor' else 16)
 
 
 N_ROLL = max(8, N_SEEDS // 4)

@@ -13,10 +13,10 @@ FIELDS = ('agents', 'dyn_prev', 'gt', 'dmap', 'drone', 'target', 'counters', 'ac
 def _pair(pkg, hip, oracle, B, **pk):
     from drone2d_amd import vec_env
     planner = pk.pop('planner', 'NoMove')
+    layout = pk.pop('grid_layout', None)       # device layout of the grids (None: the library's choice); the oracle is row-major
     p = pkg.Params(planner=planner, **pk)
     ref = vec_env.VecDrone2DEnv(p, B, backend=oracle)
-    worlds = None
-    dev = vec_env.VecDrone2DEnv(p, B, backend=hip, worlds=_worlds(ref))
+    dev = vec_env.VecDrone2DEnv(p, B, backend=hip, worlds=_worlds(ref), grid_layout=layout)
     return dev, ref
 
 
@@ -35,7 +35,7 @@ def _worlds(env):
 def _assert_same(dev, ref, tag):
     dev.sync()
     for name in FIELDS:
-        a, b = dev.state.t[name].cpu(), ref.state.t[name]
+        a, b = dev.state.logical(name).cpu(), ref.state.t[name]      # grids in the reference's [W][H] whatever the device layout
         if not torch.equal(a, b):
             bad = (a != b).nonzero()
             raise AssertionError(f'{tag}: field {name} differs at {bad[:5].tolist()} ({len(bad)} elements)')
@@ -167,16 +167,18 @@ def _cfg5_poses(worlds, t):
     return torch.tensor(out, dtype=torch.float64)
 
 
-def test_config5_geometry_vs_oracle(pkg, hip, oracle):
-    """BASELINE config 5's geometry (640 x 640 cells, 640 rays = 10 lane passes per env, 100 agents; the generic kernel
+@pytest.mark.parametrize('layout', ['rowmajor', 'tiled'])
+def test_config5_geometry_vs_oracle(pkg, hip, oracle, layout):
+    """(Both device layouts of the grids: the reference's row-major [W][H] and 16 x 16-cell tiles, d2d_cfg.grid_tile.)
+    BASELINE config 5's geometry (640 x 640 cells, 640 rays = 10 lane passes per env, 100 agents; the generic kernel
     instantiation, no LDS coverage bitmap, 400 KB grids per env): 4 worlds x 6 steps, device == oracle in every field.
     The oracle itself replays the reference's own trace at this geometry (golden `nomove_cfg5_640`)."""
     from drone2d_amd import vec_env
     worlds = _cfg5_worlds(pkg, 4)
     p = pkg.Params(planner='NoMove', map_id=5, **CFG5)
     ref = vec_env.VecDrone2DEnv(p, 4, backend=oracle, worlds=worlds)
-    dev = vec_env.VecDrone2DEnv(p, 4, backend=hip, worlds=worlds)
-    assert dev.cfg.R == 640 and dev.cfg.W == 640 and dev.cfg.N == 100
+    dev = vec_env.VecDrone2DEnv(p, 4, backend=hip, worlds=worlds, grid_layout=layout)
+    assert dev.cfg.R == 640 and dev.cfg.W == 640 and dev.cfg.N == 100 and dev.cfg.grid_tile == (16 if layout == 'tiled' else 0)
     rng = np.random.RandomState(5)
     for t in range(6):
         a = rng.uniform(-1, 1, 4)
@@ -188,7 +190,7 @@ def test_config5_geometry_vs_oracle(pkg, hip, oracle):
         ref.step(a)
         dev.sync()
         for name in FIELDS:
-            assert torch.equal(dev.state.t[name].cpu(), ref.state.t[name]), f'config 5: {name} at step {t + 1}'
+            assert torch.equal(dev.state.logical(name).cpu(), ref.state.t[name]), f'config 5: {name} at step {t + 1}'
     assert int(ref.state.hit.sum()) > 0 and int((ref.state.flags[:, 0] == 1).sum()) > 0    # rays hit agents, a wall collision
 
 
