@@ -348,6 +348,8 @@ def main():
     ap.add_argument('--large', type=int, default=65536,
                     help='envs of the large-batch legs reported beside the headline (the same kernels where launch ramp and the tail '
                          'of slow envs are amortised: the throughput regime); 0 = skip')
+    ap.add_argument('--grid-layout', default=None, choices=['rowmajor', 'tiled'],
+                    help='device layout of the two grids (default: the library\'s choice -- 16 x 16-cell tiles above 256 x 256 cells)')
     ap.add_argument('--distinct-worlds', type=int, default=0,
                     help='build only this many seeded worlds per rank and tile them over the batch (0 = one world per env)')
     args = ap.parse_args()
@@ -395,11 +397,12 @@ def main():
 
     if closed:
         env = vec_env.VecDrone2DEnv(params, B, device=device, planner='Primitive', env_offset=rank * B, worlds=worlds,
-                                    device_plugins=True, gaze='Oxford')
+                                    device_plugins=True, gaze='Oxford', grid_layout=args.grid_layout)
         if args.no_persistent:
             env._plan.launch_args = None
     else:
-        env = vec_env.VecDrone2DEnv(params, B, device=device, planner='NoMove', env_offset=rank * B, worlds=worlds)
+        env = vec_env.VecDrone2DEnv(params, B, device=device, planner='NoMove', env_offset=rank * B, worlds=worlds,
+                                    grid_layout=args.grid_layout)
     device = env.device                     # a CPU backend injected by a dry-run harness reports 'cpu'
     coll_dev = device if args.dist_backend == 'nccl' else 'cpu'
     clock = Clock(torch, device)
@@ -470,7 +473,8 @@ def main():
             if closed:
                 window['searches_per_env_per_step'] = float((env.plugins.t['plan_stat'][:, 0] - pstat0).double().mean()) / K
             cfgd = {'workload': descr.format(B=B), 'name': args.workload, 'envs_per_gpu': B, 'agents': env.N,
-                    'grid': [env.cfg.W, env.cfg.H], 'rays': env.cfg.R, 'prologue_steps': args.prologue,
+                    'grid': [env.cfg.W, env.cfg.H], 'grid_layout': 'tiled 16x16' if env.cfg.grid_tile else 'row-major [W][H]',
+                    'rays': env.cfg.R, 'prologue_steps': args.prologue,
                     'distinct_worlds_per_gpu': nw, 'auto_reset': True, 'kalman_trackers': 'on device', 'timed_window': window}
             if closed:
                 cfgd.update({'gaze': 'Oxford on the device (yaw_planner.py:41-127), every step',
@@ -506,7 +510,7 @@ def main():
         sshape = {'workload': args.workload, 'envs': B}
         if args.leg in ('all', 'step'):       # after the timed region, on its own state
             env_hot = vec_env.VecDrone2DEnv(params, B, device=device, planner='external' if closed else 'NoMove',
-                                            env_offset=rank * B, worlds=worlds)
+                                            env_offset=rank * B, worlds=worlds, grid_layout=args.grid_layout)
             us, reps = stage_leg(torch, clock, env_hot, params, rank, B, 'step')
             line['step_kernel'] = {
                 'kernel': 'k_stages (fused Drone2DEnv2.step: agents, raycast, dynamic grid, trackers, control, collision, obs)',

@@ -55,7 +55,8 @@ def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 240
     workers = int(sys.argv[2]) if len(sys.argv) > 2 else 6
     per = 10
-    jobs = [(50000 + i * per, per, i % 3 == 2) for i in range((n + per - 1) // per)]
+    seed_base = int(os.environ.get('LIVE_SWEEP_SEED', 50000))      # a new round sweeps fresh seeds
+    jobs = [(seed_base + i * per, per, i % 3 == 2) for i in range((n + per - 1) // per)]
     with ProcessPoolExecutor(workers) as ex:
         res = list(ex.map(chunk, jobs))
     out = dict(episodes=sum(r['episodes'] for r in res), steps=sum(r['steps'] for r in res),

@@ -294,6 +294,15 @@ def gen_closed():
     # returns True with an EMPTY trajectory (traj_planner.py:158-160, 204-216), the drone stays and the goal test passes
     cases['closed_oxford_goal_at_start'] = dict(agent_number=10, agent_radius=12, agent_max_speed=20, map_id=11,
                                                 target_list=[[47, 55], [122, 113]])
+    # BASELINE configs 3 and 4 and a non-default map size, closed loop (round 3: until then every closed-loop fixture sat on the
+    # 500 x 500 empty map with N <= 20).  Config 3 from the default start (50, 50) dies by collision within a few steps
+    # (SURVEY 8d), hence the start below the field of random_map_0's agents.
+    cases['closed_oxford_config3'] = dict(agent_number=50, agent_radius=10, agent_max_speed=40, map_id=1, drone_max_speed=40,
+                                          static_map='maps/random_map_0.npy', init_pos=[250, 30])
+    cases['closed_oxford_config4'] = dict(agent_number=10, agent_radius=15, agent_max_speed=20, map_id=1, drone_max_speed=40,
+                                          static_map='maps/obstacle_map.npy')
+    cases['closed_oxford_map1000x800'] = dict(agent_number=14, agent_radius=12, agent_max_speed=30, map_id=21, map_size=[1000, 800],
+                                              drone_view_range=120, init_pos=[80, 90], target_list=[[900, 700]])
     only = sys.argv[2:] if len(sys.argv) > 2 and sys.argv[1] == 'closed' else None
     for name, kw in cases.items():
         if only and name not in only:
@@ -314,7 +323,7 @@ def gen_live(outdir, seed0, count, wide=False, scale20=False):
                   map_id=int(rng.randint(0, 10000)), pillar_number=int(rng.choice([0, 0, 3, 6, 9])),
                   drone_view_range=int(rng.choice([60, 90, 90, 120])), drone_view_depth=int(rng.choice([60, 80, 80, 100])))
         if rng.rand() < 0.25:
-            kw['static_map'] = str(rng.choice(['maps/obstacle_map.npy', 'maps/shaped_obstacle_map.npy']))
+            kw['static_map'] = str(rng.choice(['maps/obstacle_map.npy', 'maps/shaped_obstacle_map.npy', 'maps/random_map_0.npy']))   # (random_map_0: round 3)
         if rng.rand() < 0.3:
             kw['target_list'] = [[int(rng.randint(40, 460)), int(rng.randint(40, 460))], [int(rng.randint(40, 460)), int(rng.randint(40, 460))]]
         if rng.rand() < 0.3:

@@ -126,5 +126,7 @@ TRACES_PLANNED = ['readme_oxford_primitive', 'lookahead_primitive_n30_map0', 'lo
                   'deadlock_primitive']
 TRACES_CLOSED = ['closed_oxford_n20_map0', 'closed_oxford_n20_map5', 'closed_oxford_pillars_map2', 'closed_oxford_pillars_map6',
                  'closed_oxford_slow_drone', 'closed_oxford_fast_drone', 'closed_oxford_fov120', 'closed_oxford_two_targets',
-                 'closed_oxford_goal_at_start', 'closed_oxford_short_view_d50']
+                 'closed_oxford_goal_at_start', 'closed_oxford_short_view_d50',
+                 # round 3: BASELINE configs 3 (random_map_0, 172 agents) and 4 (obstacle_map, 24 agents), a 1000 x 800 px map with a 120 degree view
+                 'closed_oxford_config3', 'closed_oxford_config4', 'closed_oxford_map1000x800']
 ALL_TRACES = TRACES_NOMOVE + TRACES_PLANNED + TRACES_CLOSED

@@ -24,7 +24,9 @@ else:
     params = pkg.Params(planner='Primitive', agent_number=int(os.environ.get('N', 10)), agent_radius=int(os.environ.get('R', 15)),
                         agent_max_speed=20, map_id=1, **extra)
 worlds = vec_env.build_worlds(params, min(B, int(os.environ.get('WORLDS', 512))), workers=int(os.environ.get('WORKERS', 0)))
-env = vec_env.VecDrone2DEnv(params, B, planner='external', worlds=[worlds[i % len(worlds)] for i in range(B)])
+env = vec_env.VecDrone2DEnv(params, B, planner='external', worlds=[worlds[i % len(worlds)] for i in range(B)],
+                            grid_layout=os.environ.get('LAYOUT') or None)     # LAYOUT=rowmajor | tiled (default: the library's choice)
+print('grid layout:', 'tiled 16x16' if env.cfg.grid_tile else 'row-major', flush=True)
 T = 260
 g = torch.Generator().manual_seed(1)
 actions = (torch.rand(T, B, generator=g, dtype=torch.float64) * 2 - 1).cuda()
