@@ -18,8 +18,9 @@ that the timed window holds episode ends, restarts and the steady search rate ev
 line reports `searches_per_env_per_step` and `episode_ends` OF THE TIMED WINDOW.
 
 Other BASELINE configurations: --workload config3 | config4 | config5 (envs per GPU: 65536 / 32768 / 32768, override
-with --envs).  config5 (640 x 640 cells, 640 rays, 100 agents) names no plugins and its maps are beyond the plugin
-stages' LDS working sets: its step is the fused Drone2DEnv2.step alone (NoMove), fixed-seed gaze actions.
+with --envs); config5 (640 x 640 cells, 640 rays, 100 agents) runs the closed loop like the others since round 3, config5-step
+its fused Drone2DEnv2.step alone (NoMove, fixed-seed gaze actions: the figure of rounds 1 and 2).  The BASELINE jobs of 262144
+envs are `--workload config4 --gpus 8` and `--workload config5 --gpus 8` (32768 envs per GPU).
 
 Besides the headline the line carries, measured after the timed region with HIP events on the launch stream:
   step_kernel    the fused Drone2DEnv2.step kernel alone (k_stages; actions and planner heads resident in HBM)
@@ -60,9 +61,13 @@ WORKLOADS = {
     'config4': (32768, dict(agent_number=10, agent_radius=15, agent_max_speed=20, static_map='maps/obstacle_map.npy'), True,
                 'configs[3]: {B} envs per GPU (262144 over 8) x 10 agents + 14 obstacle_map agents, Oxford + Primitive'),
     'config5': (32768, dict(agent_number=100, agent_radius=15, agent_max_speed=40, map_size=[6400, 6400], init_pos=[3200, 3200],
-                            target_list=[[6000, 6000]]), False,
-                'configs[4]: {B} envs per GPU (262144 over 8) x 100 agents, 640x640 uint8 grid, 640 rays; fused '
-                'Drone2DEnv2.step (NoMove), fixed-seed gaze actions'),
+                            target_list=[[6000, 6000]]), True,
+                'configs[4]: {B} envs per GPU (262144 over 8) x 100 agents, 640x640 uint8 grid (16x16-cell tiles), 640 rays, '
+                'Oxford + Primitive (round 3: the device plugins take maps of this size)'),
+    'config5-step': (32768, dict(agent_number=100, agent_radius=15, agent_max_speed=40, map_size=[6400, 6400], init_pos=[3200, 3200],
+                                 target_list=[[6000, 6000]]), False,
+                     'configs[4] geometry, the fused Drone2DEnv2.step alone: {B} envs per GPU x 100 agents, 640x640 uint8 grid, 640 rays; '
+                     'NoMove, fixed-seed gaze actions (what rounds 1 and 2 reported as config 5)'),
 }
 
 
@@ -371,6 +376,8 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     B0, pkw, closed, descr = WORKLOADS[args.workload]
+    if args.workload.startswith('config5'):
+        args.large = 0          # 32768 envs of 0.8 MB are the large batch already (65536 of them would not fit beside the legs)
     B, K, Wm = (args.envs or B0), args.steps, args.warmup
     params = pkg.Params(planner='Primitive' if closed else 'NoMove', gaze_method='Oxford' if closed else 'NoControl',
                         drone_max_speed=40, map_id=1, **pkw)

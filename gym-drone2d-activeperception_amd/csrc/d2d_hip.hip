@@ -126,6 +126,18 @@ struct FastDiv {
     q = (int)(((float)idx + 0.5f) * inv);
     r = idx - q * d;
   }
+  // any 0 <= idx < 2^24 (cell indices of a large grid: the float quotient can be one off), with the fix-up
+  __device__ __forceinline__ void divmod_big(int idx, int &q, int &r) const {
+    q = (int)(((float)idx + 0.5f) * inv);
+    r = idx - q * d;
+    if (r < 0) {
+      q -= 1;
+      r += d;
+    } else if (r >= d) {
+      q += 1;
+      r -= d;
+    }
+  }
 };
 
 struct LdsView {
@@ -2066,6 +2078,9 @@ int plan_check(const d2d_cfg *c, const d2d_state *s, const d2d_plan *p) {
     if (p->pw_nleaf <= 0 || p->pw_nprog != 2 * p->pw_nleaf - 1 || p->pw_ntree < 3) return fail(-1, "gaze: bad pairwise-sum program");
     if ((size_t)gaze_geom(*c, *p).wave_bytes > LDS_HARD)
       return fail(-4, "gaze: map / view depth too large for the per-env LDS working set");
+    if (gaze_geom(*c, *p).sparse && gaze_geom(*c, *p).bbn > 32)
+      return fail(-4, "gaze: view depth above 13 cells on a map of more than 4096 cells (two blocks of numpy's pairwise sum per box row, 64 in all)");
+    if ((long long)c->W * c->H >= (1ll << 24)) return fail(-4, "gaze: maps of 2^24 cells and more are not supported");
     if (gaze_geom(*c, *p).bbn > 64 || c->W * c->H < 64)
       return fail(-4, "gaze: view depth above 29 cells or a map below 64 cells");
     if (c->max_steps + 2 > (double)p->tobs_len) return fail(-1, "gaze: tobs_tab shorter than the longest episode");

@@ -1094,9 +1094,19 @@ __device__ __forceinline__ CellBox sector_box(double cx, double cy, double depth
 }
 
 #define D2D_TOBS_LDS 16
+// Maps above this many cells: the pairwise-summation plan of np.sum over W x H (one block per <= 128 cells + the tree of their
+// additions) no longer fits the wave's LDS.  Only blocks that hold a non-zero term matter (x + 0.0 == x, every term is >= +0.0) and
+// those lie inside the view box: the SPARSE path finds them by walking numpy's recursion down from the root for the box's cells and
+// adds their sums up the same recursion -- no table of the W x H plan on the device at all (gaze_env).
+#define D2D_GAZE_DENSE_CELLS 4096
+#define D2D_GAZE_HOT 64     // blocks with a non-zero term the sparse path holds (two per box row: a block has >= 64 cells)
 struct GazeGeom {
   int bbn;    // cells per axis of the bounding box of a view disk
   int ncell;  // bbn * bbn
+  int sparse; // the sparse pairwise path (maps above D2D_GAZE_DENSE_CELLS cells)
+  int nleaf;  // block records kept in LDS: pw_nleaf, or D2D_GAZE_HOT
+  int ntree;  // ints of the addition tree kept in LDS: pw_ntree, or 0
+  int nnode;  // sums per candidate: blocks + additions, or D2D_GAZE_HOT
   int wave_bytes;
 };
 
@@ -1104,10 +1114,14 @@ __host__ __device__ inline GazeGeom gaze_geom(const d2d_cfg &c, const d2d_plan &
   GazeGeom g;
   g.bbn = 2 * ((int)(c.depth / c.scale) + 1) + 3;
   g.ncell = g.bbn * g.bbn;
+  g.sparse = (c.W * c.H > D2D_GAZE_DENSE_CELLS) ? 1 : 0;
+  g.nleaf = g.sparse ? D2D_GAZE_HOT : p.pw_nleaf;
+  g.ntree = g.sparse ? 2 * D2D_GAZE_HOT : p.pw_ntree;  // sparse: depth and path of every hot block in numpy's recursion
+  g.nnode = g.sparse ? D2D_GAZE_HOT : 2 * p.pw_nleaf - 1;
   // int swept index + double reward + candidate bits per box cell, block sums + add stacks per candidate, the plan
-  const int sums = 8 * p.n_yaw * (2 * p.pw_nleaf - 1), live = 4 * g.ncell;  // the live-cell list shares the sums' space
+  const int sums = 8 * p.n_yaw * g.nnode, live = 4 * g.ncell;  // the live-cell list shares the sums' space
   const int bytes = 4 * g.ncell + 8 * g.ncell + ((g.ncell + 7) & ~7) + (((sums > live ? sums : live) + 7) & ~7) + 8 * 16 +
-                    4 * (4 * p.pw_nleaf + p.pw_ntree) + 16 + 8 * D2D_TOBS_LDS;  // + row / column masks of the non-zero terms, table head
+                    4 * (4 * g.nleaf + g.ntree) + 16 + 8 * D2D_TOBS_LDS;  // + row / column masks of the non-zero terms, table head
   g.wave_bytes = (bytes + 15) & ~15;
   return g;
 }
@@ -1128,7 +1142,7 @@ __device__ __forceinline__ void gaze_env(const d2d_cfg &c, const d2d_state &s, c
   if (p.gaze != D2D_GAZE_OXFORD) return;
   const GazeGeom g = gaze_geom(c, p);
   double *rew = (double *)base;                                   // [ncell]
-  const int nnode = 2 * p.pw_nleaf - 1;                           // blocks + their pairwise sums up to the root
+  const int nnode = g.nnode;                                      // blocks + their pairwise sums up to the root (sparse: the hot blocks)
   double *lsum = rew + g.ncell;                                   // [n_yaw][nnode]
   const int lsum_doubles = max(p.n_yaw * nnode, (g.ncell + 1) / 2);
   double *stk = lsum + lsum_doubles;                              // [8][2] view directions
@@ -1136,8 +1150,8 @@ __device__ __forceinline__ void gaze_env(const d2d_cfg &c, const d2d_state &s, c
   int *swi = (int *)(tobl + D2D_TOBS_LDS);                        // [ncell]
   int *swl = (int *)lsum;                                         // [ncell] the live cells of the box: done before the sums start
   int *pwl = swi + g.ncell;                                       // [pw_nleaf][4] + [pw_ntree]: the pairwise plan
-  int *pwp = pwl + 4 * p.pw_nleaf;
-  unsigned char *cm = (unsigned char *)(pwp + p.pw_ntree);        // [ncell]
+  int *pwp = pwl + 4 * g.nleaf;
+  unsigned char *cm = (unsigned char *)(pwp + g.ntree);           // [ncell]
   int *rng = (int *)(cm + ((g.ncell + 7) & ~7));                  // [2] first / last grid row with a non-zero term of any sum
   const int W = c.W, H = c.H;
   const double deg2rad = 0x1.1df46a2529d39p-6;                    // math.radians
@@ -1156,8 +1170,10 @@ __device__ __forceinline__ void gaze_env(const d2d_cfg &c, const d2d_state &s, c
   }
   // the pairwise plan (a few hundred bytes) into LDS with one coalesced read; used only after several barriers
   if (lane < D2D_TOBS_LDS) tobl[lane] = p.tobs_tab[min(lane, p.tobs_len - 1)];  // the entries below 1 (reward = the value itself)
-  for (int k = lane; k < 4 * p.pw_nleaf; k += WAVE) pwl[k] = p.pw_leaf[k];
-  for (int k = lane; k < p.pw_ntree; k += WAVE) pwp[k] = p.pw_tree[k];
+  if (!g.sparse) {
+    for (int k = lane; k < 4 * p.pw_nleaf; k += WAVE) pwl[k] = p.pw_leaf[k];
+    for (int k = lane; k < p.pw_ntree; k += WAVE) pwp[k] = p.pw_tree[k];
+  }
   const FastDiv fdb(g.bbn);
   // shortcut of view_cell: only for cones narrower than 180 degrees whose edge is well inside (0, 1); cos(half_fov)
   // is the double in the middle of the host's arccos window
@@ -1411,7 +1427,50 @@ __device__ __forceinline__ void gaze_env(const d2d_cfg &c, const d2d_state &s, c
   // the blocks that cover a row with a non-zero term, compacted in order: lane = block (their row ranges are in LDS)
   int *hlist = swi;  // the swept map is not needed any more
   int nhl = 0;
-  for (int l0 = 0; l0 < p.pw_nleaf; l0 += WAVE) {
+  if (g.sparse) {
+    // The blocks that can hold a non-zero term: for every box row with one, the block of its first and of its last column with one
+    // (a block has >= 64 cells, the columns span < 64: there is none in between).  numpy's recursion (loops_utils.h.src pairwise_sum:
+    // n <= 128 is a block, else split at n / 2 rounded down to a multiple of 8) is walked down from the root for that cell: the block
+    // [off, off + m), its depth and its path (one bit per split, 1 = right half).  Lane = (row, first / last), in cell order.
+    const int r = lane >> 1, i = row_lo + r;
+    const bool on = i <= row_hi && ((hrows >> (i - bi)) & 1ull) != 0ull;
+    const int gcell = i * H + ((lane & 1) ? jhi - 1 : jlo);
+    int off = 0, m = W * H, depth = 0, path = 0;
+    while (__any(on && m > 128)) {
+      if (m > 128) {
+        int m2 = m >> 1;
+        m2 -= m2 & 7;
+        const bool right = gcell >= off + m2;
+        off = right ? off + m2 : off;
+        m = right ? m - m2 : m2;
+        path = (path << 1) | (right ? 1 : 0);
+        depth += 1;
+      }
+    }
+    // the same block twice (first and last column in one block, or a block that spans two rows): lanes are in cell order, so equal
+    // blocks are neighbours among the lanes that are on
+    const unsigned long long om = __ballot(on);
+    const unsigned long long below = om & ((1ull << lane) - 1ull);
+    const int prev = below ? 63 - __clzll((long long)below) : lane;
+    const int off_prev = __shfl(off, prev, WAVE);
+    const bool isnew = on && (below == 0ull || off_prev != off);
+    const unsigned long long nm = __ballot(isnew);
+    nhl = __popcll(nm);  // <= D2D_GAZE_HOT: 2 lanes per row, at most 32 rows (plan_check: bbn <= 32 on such maps)
+    if (isnew) {
+      const int k = __popcll(nm & ((1ull << lane) - 1ull));
+      int i_first, i_last, dummy;
+      fdh.divmod_big(off, i_first, dummy);
+      fdh.divmod_big(off + m - 1, i_last, dummy);
+      pwl[4 * k] = off;
+      pwl[4 * k + 1] = m;
+      pwl[4 * k + 2] = i_first;
+      pwl[4 * k + 3] = i_last;
+      pwp[k] = depth;
+      pwp[D2D_GAZE_HOT + k] = path;
+      hlist[k] = k;
+    }
+  }
+  for (int l0 = 0; !g.sparse && l0 < p.pw_nleaf; l0 += WAVE) {
     const int lf = min(l0 + lane, p.pw_nleaf - 1);
     const int i_first = pwl[4 * lf + 2], i_last = pwl[4 * lf + 3];
     const int lo = max(max(i_first, row_lo) - bi, 0), hi = min(min(i_last, row_hi) - bi, 63);
@@ -1470,7 +1529,7 @@ __device__ __forceinline__ void gaze_env(const d2d_cfg &c, const d2d_state &s, c
         if ((m & 7) != 0 && r_of == 0 && live)
           for (int k = m - (m & 7); k < m; ++k) {  // numpy adds the block's last m % 8 elements one by one after the fold
             int gi, gj;
-            fdh.divmod(off + k, gi, gj);
+            fdh.divmod_big(off + k, gi, gj);
             const int r = gi - bi, cc = gj - bj;
             double x = 0.0;
             if (r >= 0 && r < g.bbn && cc >= 0 && cc < g.bbn && ((cm[r * g.bbn + cc] >> a) & 1)) x = rew[r * g.bbn + cc];
@@ -1489,6 +1548,60 @@ __device__ __forceinline__ void gaze_env(const d2d_cfg &c, const d2d_state &s, c
 #endif
   // ---- the blocks' sums added in the recursion's order, level by level: the additions of one level are independent
   //      (lane = (candidate, addition)), every single one keeps numpy's left + right; argmax below (:116-125) ----
+  if (g.sparse) {
+    // lane = hot block, in cell order = the order of the recursion's leaves.  Deepest level first: two blocks whose paths differ in
+    // the last bit only are the two halves of one split -- left + right, numpy's operand order; a half without a partner has a
+    // sibling that sums to +0.0, and x + 0.0 == x == 0.0 + x for the x >= +0.0 there are: it moves up unchanged.
+    bool alive = lane < nhl;
+    int depth = alive ? pwp[lane] : 0, path = alive ? pwp[D2D_GAZE_HOT + lane] : 0;
+    double val[7];
+#pragma unroll
+    for (int a = 0; a < 7; ++a) val[a] = (alive && a < p.n_yaw) ? lsum[a * nnode + lane] : 0.0;
+    int maxd = depth;
+    for (int o = 32; o > 0; o >>= 1) maxd = max(maxd, __shfl_xor(maxd, o, WAVE));
+    for (int D = maxd; D >= 1; --D) {
+      const unsigned long long am = __ballot(alive);
+      const unsigned long long above = lane < 63 ? (am >> (lane + 1)) : 0ull;
+      const int nx = above ? lane + 1 + (__ffsll((long long)above) - 1) : lane;
+      const int dn = __shfl(depth, nx, WAVE), pn = __shfl(path, nx, WAVE);
+      const bool adv = alive && depth == D;
+      const bool left = adv && above != 0ull && dn == D && (pn >> 1) == (path >> 1) && (path & 1) == 0 && (pn & 1) == 1;
+      const unsigned long long lm = __ballot(left);
+      if (__builtin_amdgcn_readfirstlane((int)(lm != 0ull))) {
+#pragma unroll
+        for (int a = 0; a < 7; ++a) {
+          if (a < p.n_yaw) {
+            const double vn = shfl_f64(val[a], nx);
+            if (left) val[a] = val[a] + vn;
+          }
+        }
+      }
+      // the right half of a pair is done: it is the lane whose previous live lane added it
+      const unsigned long long below = am & ((1ull << lane) - 1ull);
+      const int pv = below ? 63 - __clzll((long long)below) : 0;
+      const bool right = alive && below != 0ull && ((lm >> pv) & 1ull) != 0ull;
+      if (adv) {
+        depth -= 1;
+        path >>= 1;
+      }
+      if (right) alive = false;
+    }
+    // the root is the first hot block's lane
+    int best = 0;
+    double max_reward = 0.0;
+    for (int a = 0; a < p.n_yaw; ++a) {
+      double r = 0.0;
+#pragma unroll
+      for (int b = 0; b < 7; ++b) r = (b == a) ? val[b] : r;
+      r = shfl_f64(r, 0);
+      if (max_reward < r) {
+        best = a;
+        max_reward = r;
+      }
+    }
+    if (lane == 0) act[e] = p.yaw_space[best] / p.yaw_rate_max;  // :127
+    return;
+  }
   {
     const int nlev = pwp[0];
     const int *lstart = pwp + 2, *ops = pwp + 3 + nlev;

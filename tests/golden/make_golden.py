@@ -385,7 +385,18 @@ def gen_cfg5():
     save('nomove_cfg5_640', run_trace(p, len(acts), actions=acts, teleport=tele, stop_on_done=False))
 
 
+def gen_cfg5_closed():
+    """BASELINE config 5's geometry with Oxford + Primitive (round 3: the device plugins took maps of this size from then on): the drone
+    starts 130 px from where agent 7 of this seed passes by within the first seconds, so that trackers start and the planner has
+    something to avoid.  45 steps of the reference's own closed loop."""
+    p = make_params(gaze_method='Oxford', planner='Primitive', agent_number=100, agent_radius=15, agent_max_speed=40, map_id=5,
+                    drone_max_speed=40, map_size=[6400, 6400], init_pos=[940, 5000], target_list=[[6000, 6000]])
+    save('closed_oxford_cfg5_640', run_trace(p, 45, policy='Oxford'))
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == 'cfg5closed':
+        return gen_cfg5_closed()
     if len(sys.argv) > 1 and sys.argv[1] == 'cfg5':
         return gen_cfg5()
     if len(sys.argv) > 1 and sys.argv[1] == 'short_view':

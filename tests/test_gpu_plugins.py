@@ -50,7 +50,7 @@ def _pair(pkg, hip, oracle, B, **pk):
 def _assert_same(dev, ref, tag):
     dev.sync()
     for name in FIELDS + ('action', 'plan_ok', 'wp_valid', 'wp'):
-        a, b = dev.state.t[name].cpu(), ref.state.t[name]
+        a, b = dev.state.logical(name).cpu(), ref.state.t[name]     # grids in [W][H] whatever the device layout
         if not torch.equal(a, b):
             bad = (a != b).nonzero()
             raise AssertionError(f'{tag}: field {name} differs at {bad[:5].tolist()} ({len(bad)} elements)')
@@ -248,3 +248,38 @@ def _with_map(p, map_id):
     q = copy.copy(p)
     q.map_id = map_id
     return q
+
+
+@pytest.mark.parametrize('layout', ['rowmajor', 'tiled'])
+def test_config5_closed_loop_vs_oracle(pkg, hip, oracle, layout):
+    """BASELINE config 5's geometry (640 x 640 cells, 640 rays, 100 agents) with Oxford and Primitive ON THE DEVICE -- refused until
+    round 3 (-4: the W x H pairwise-summation plan did not fit the wave's LDS).  The gaze stage now finds the blocks of numpy's
+    pairwise sum that hold a non-zero term by walking the recursion (sparse path, d2d_plugins.h), the planner probes the explored
+    map in HBM.  4 worlds x 40 steps with auto reset, drones started next to agents of their worlds (trackers, replans), both grid
+    layouts: every field of the env and plugin state equals the oracle's, bit for bit."""
+    from drone2d_amd import vec_env
+    from test_gpu_vs_oracle import CFG5, _cfg5_poses
+    p = pkg.Params(planner='Primitive', gaze_method='Oxford', drone_max_speed=40, map_id=5, **CFG5)
+    ref = vec_env.VecDrone2DEnv(p, 4, backend=oracle, planner='Primitive', device_plugins=True, gaze='Oxford')
+    worlds = _worlds(ref)
+    dev = vec_env.VecDrone2DEnv(p, 4, backend=hip, planner='Primitive', device_plugins=True, gaze='Oxford', worlds=worlds,
+                                grid_layout=layout)
+    assert dev.cfg.W == 640 and dev.cfg.R == 640 and dev.cfg.grid_tile == (16 if layout == 'tiled' else 0)
+    # three drones start 45 px below an agent of their world, looking at it (yaw 270 looks along +y), one in the open field
+    from drone2d_amd import _abi as A
+    ag = ref.state.agents
+    xy = torch.stack([ag[:, A.A_PX, 7].floor() + 6.0, ag[:, A.A_PY, 7].floor() - 45.0], dim=1).clamp(40.0, 6360.0)
+    xy[0] = torch.tensor([3200., 3200.])
+    for env in (dev, ref):
+        env.state.drone[:, :2] = xy.to(env.device)
+    tracked = 0
+    oracle.lib.d2d_oracle_set_threads(8)
+    try:
+        for t in range(0, 40, 4):
+            dev.closed_loop(4, auto_reset=True)
+            ref.closed_loop(4, auto_reset=True)
+            _assert_same(dev, ref, f'config 5 closed loop ({layout}) after step {t + 4}')
+            tracked = max(tracked, int(ref.state.active.sum()))
+    finally:
+        oracle.lib.d2d_oracle_set_threads(1)
+    assert int(ref.plugins.t['plan_stat'][:, 0].sum()) >= 4 and tracked > 0   # searches ran, trackers were active on the way

@@ -27,11 +27,11 @@ for i, t in enumerate(toks):
     if t == '--chunk':
         CHUNK = int(toks[i + 1])
 if '--envs' not in toks:
-    ENVS = {'config2': 4096, 'config3': 65536, 'config4': 32768, 'config5': 32768}[WORKLOAD]
+    ENVS = {'config2': 4096, 'config3': 65536, 'config4': 32768, 'config5': 32768, 'config5-step': 32768}[WORKLOAD]
 # leg -> (kernel-name prefix of interest, key in pmc_latest.json, env-steps per launch)
 LEGS = {'closed': ('k_closed<', 'k_closed', ENVS * CHUNK), 'step': ('k_stages<', 'k_stages', ENVS),
         'raycast': ('k_stages<', 'raycast_stage', ENVS)}
-if WORKLOAD == 'config5':
+if WORKLOAD == 'config5-step':      # a non-persistent workload: its timed leg is k_stages launches
     LEGS['closed'] = ('k_stages<', 'k_stages_timed', ENVS)
 
 
