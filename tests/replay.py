@@ -128,5 +128,6 @@ TRACES_CLOSED = ['closed_oxford_n20_map0', 'closed_oxford_n20_map5', 'closed_oxf
                  'closed_oxford_slow_drone', 'closed_oxford_fast_drone', 'closed_oxford_fov120', 'closed_oxford_two_targets',
                  'closed_oxford_goal_at_start', 'closed_oxford_short_view_d50',
                  # round 3: BASELINE configs 3 (random_map_0, 172 agents) and 4 (obstacle_map, 24 agents), a 1000 x 800 px map with a 120 degree view
-                 'closed_oxford_config3', 'closed_oxford_config4', 'closed_oxford_map1000x800']
+                 'closed_oxford_config3', 'closed_oxford_config4', 'closed_oxford_map1000x800',
+                 'closed_oxford_cfg5_640']    # config 5's geometry: 640 x 640 cells, 640 rays, 100 agents, Oxford + Primitive
 ALL_TRACES = TRACES_NOMOVE + TRACES_PLANNED + TRACES_CLOSED
