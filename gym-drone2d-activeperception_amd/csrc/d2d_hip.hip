@@ -745,10 +745,10 @@ __device__ __forceinline__ void ray_march(const GX &gx, const d2d_cfg &c, const 
     // garbage position just reads some tile byte that is then ignored); it must not become a select between
     // an LDS and a global pointer (flat load + vmcnt(0) wait per sample).
     const int ci = cell(x), cj = cell(y);
-    int gi = 0;
+    unsigned int gi = 0;  // unsigned: a 32-bit byte offset on the env's scalar base pointer, no 64-bit address arithmetic per sample
     unsigned char wall;
     if constexpr (FULL) {
-      gi = alive ? ci * H + cj : 0;  // a live sample lies inside the map (0 < x < W_px): the index is the cell's own
+      gi = alive ? (unsigned int)(ci * H + cj) : 0u;  // a live sample lies inside the map (0 < x < W_px): the index is the cell's own
       wall = gtw[gi];
     } else {
       const int wr = min(max(ci - wt.i0, 0), wt.rows - 1), wq = min(max(cj - wt.j0, 0), wt.cols - 1);
@@ -765,7 +765,7 @@ __device__ __forceinline__ void ray_march(const GX &gx, const d2d_cfg &c, const 
         if (patch) dmt[gi] = v;  // the copy the observation crop is cut from
       } else {
 #ifndef D2D_ABL_NOSTORE
-        dm[gx(ci, cj)] = v;
+        dm[(unsigned int)gx(ci, cj)] = v;
 #endif
         const unsigned int pr = (unsigned int)(ci - ct.i0), pq = (unsigned int)(cj - ct.j0);  // observation tile in step
         if (patch && pr < (unsigned int)ct.rows && pq < (unsigned int)ct.cols) dmt[pr * ct.cols + pq] = v;

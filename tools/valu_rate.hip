@@ -89,6 +89,23 @@ KERNEL(k_add_u32_d, unsigned int, 3u, DEP2("v_add_u32"))
 KERNEL(k_lshl_b32_i, unsigned int, 3u, INDEP2("v_lshlrev_b32"))
 KERNEL(k_and_b32_i, unsigned int, 3u, INDEP2("v_and_b32"))
 KERNEL(k_mad_u32_u24_i, unsigned int, 3u, INDEP64("v_mad_u32_u24"))
+KERNEL(k_or_b32_i, unsigned int, 3u, INDEP2("v_or_b32"))
+KERNEL(k_xor_b32_i, unsigned int, 3u, INDEP2("v_xor_b32"))
+KERNEL(k_lshr_b32_i, unsigned int, 3u, INDEP2("v_lshrrev_b32"))
+KERNEL(k_ashr_i32_i, unsigned int, 3u, INDEP2("v_ashrrev_i32"))
+KERNEL(k_min_u32_i, unsigned int, 3u, INDEP2("v_min_u32"))
+KERNEL(k_max_i32_i, unsigned int, 3u, INDEP2("v_max_i32"))
+KERNEL(k_sub_u32_i, unsigned int, 3u, INDEP2("v_sub_u32"))
+KERNEL(k_mov_b32_i, unsigned int, 3u, INDEP1("v_mov_b32"))
+KERNEL(k_add3_u32_i, unsigned int, 3u, INDEP64("v_add3_u32"))
+KERNEL(k_lshl_add_u32_i, unsigned int, 3u, INDEP64("v_lshl_add_u32"))
+KERNEL(k_and_or_b32_i, unsigned int, 3u, INDEP64("v_and_or_b32"))
+KERNEL(k_bfe_u32_i, unsigned int, 3u, INDEP64("v_bfe_u32"))
+KERNEL(k_cvt_f32_i32_i, unsigned int, 3u, INDEP1("v_cvt_f32_i32"))
+KERNEL(k_cvt_i32_f32_i, float, 1.0f, INDEP1("v_cvt_i32_f32"))
+KERNEL(k_floor_f32_i, float, 1.0f, INDEP1("v_floor_f32"))
+KERNEL(k_rcp_f32_i, float, 1.0f, INDEP1("v_rcp_f32"))
+KERNEL(k_mov_b64_i, double, 1.0, INDEP1("v_mov_b64"))
 
 // compares write a lane mask (vcc): 8 compares per group on 8 register pairs
 __global__ __launch_bounds__(1024) void k_cmp_f64_i(unsigned long long *out, double *sink) {
@@ -120,6 +137,58 @@ __global__ __launch_bounds__(1024) void k_cmp_f32_i(unsigned long long *out, flo
   const unsigned long long t1 = __builtin_amdgcn_s_memtime();
   if ((threadIdx.x & 63) == 0) out[threadIdx.x >> 6] = t1 - t0;
   if (a0 + a1 + a2 + a3 == -12345.0f) sink[0] = a0;
+}
+// select by a lane mask (vcc stays what the prologue left in it)
+__global__ __launch_bounds__(1024) void k_cndmask_i(unsigned long long *out, unsigned int *sink) {
+  unsigned int a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, b = 5;
+  asm volatile("" : "+v"(b));
+  __syncthreads();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+#pragma unroll 1
+  for (int i = 0; i < ITER; ++i)
+    asm volatile(REP4("v_cndmask_b32 %0, %0, %4, vcc\n v_cndmask_b32 %1, %1, %4, vcc\n v_cndmask_b32 %2, %2, %4, vcc\n v_cndmask_b32 %3, %3, %4, vcc\n"
+                      "v_cndmask_b32 %0, %0, %4, vcc\n v_cndmask_b32 %1, %1, %4, vcc\n v_cndmask_b32 %2, %2, %4, vcc\n v_cndmask_b32 %3, %3, %4, vcc\n")
+                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b) : "vcc");
+  asm volatile("s_nop 0" ::: "memory");
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  if ((threadIdx.x & 63) == 0) out[threadIdx.x >> 6] = t1 - t0;
+  if (a0 + a1 + a2 + a3 == 12345u) sink[0] = a0;
+}
+__global__ __launch_bounds__(1024) void k_cmp_u32_i(unsigned long long *out, unsigned int *sink) {
+  unsigned int a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, b = 5;
+  asm volatile("" : "+v"(b));
+  __syncthreads();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+#pragma unroll 1
+  for (int i = 0; i < ITER; ++i)
+    asm volatile(REP4("v_cmp_lt_u32 vcc, %0, %4\n v_cmp_lt_u32 vcc, %1, %4\n v_cmp_lt_u32 vcc, %2, %4\n v_cmp_lt_u32 vcc, %3, %4\n"
+                      "v_cmp_lt_u32 vcc, %0, %4\n v_cmp_lt_u32 vcc, %1, %4\n v_cmp_lt_u32 vcc, %2, %4\n v_cmp_lt_u32 vcc, %3, %4\n")
+                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b) : "vcc");
+  asm volatile("s_nop 0" ::: "memory");
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  if ((threadIdx.x & 63) == 0) out[threadIdx.x >> 6] = t1 - t0;
+  if (a0 + a1 + a2 + a3 == 12345u) sink[0] = a0;
+}
+// LDS: a dependent chain of reads (latency) and independent reads (rate)
+__global__ __launch_bounds__(1024) void k_ds_read_b32_d(unsigned long long *out, unsigned int *sink) {
+  __shared__ unsigned int buf[4096];
+  for (int i = threadIdx.x; i < 4096; i += blockDim.x) buf[i] = (unsigned int)(((i * 4) + 256) & 16383);
+  __syncthreads();
+  unsigned int a = (threadIdx.x * 4) & 16383;
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+#pragma unroll 1
+  for (int i = 0; i < ITER; ++i) {
+    unsigned int v;
+    asm volatile(REP4("ds_read_b32 %0, %1\n s_waitcnt lgkmcnt(0)\n v_mov_b32 %1, %0\n ds_read_b32 %0, %1\n s_waitcnt lgkmcnt(0)\n v_mov_b32 %1, %0\n"
+                      "ds_read_b32 %0, %1\n s_waitcnt lgkmcnt(0)\n v_mov_b32 %1, %0\n ds_read_b32 %0, %1\n s_waitcnt lgkmcnt(0)\n v_mov_b32 %1, %0\n"
+                      "ds_read_b32 %0, %1\n s_waitcnt lgkmcnt(0)\n v_mov_b32 %1, %0\n ds_read_b32 %0, %1\n s_waitcnt lgkmcnt(0)\n v_mov_b32 %1, %0\n"
+                      "ds_read_b32 %0, %1\n s_waitcnt lgkmcnt(0)\n v_mov_b32 %1, %0\n ds_read_b32 %0, %1\n s_waitcnt lgkmcnt(0)\n v_mov_b32 %1, %0\n")
+                 : "=&v"(v), "+v"(a));
+  }
+  asm volatile("s_nop 0" ::: "memory");
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  if ((threadIdx.x & 63) == 0) out[threadIdx.x >> 6] = t1 - t0;
+  if (a == 12345u) sink[0] = a;
 }
 // conversions f64 <-> i32 (the march's cell index): dst and src differ in width
 __global__ __launch_bounds__(1024) void k_cvt_i32_f64_i(unsigned long long *out, double *sink) {
@@ -217,6 +286,12 @@ int main(int argc, char **argv) {
       CASE(k_add_f32_i, float), CASE(k_pk_fma_f32_i, double), CASE(k_cmp_f32_i, float), CASE(k_mul_u24_i, unsigned int),
       CASE(k_mul_u24_d, unsigned int), CASE(k_mul_lo_u32_i, unsigned int), CASE(k_mad_u32_u24_i, unsigned int),
       CASE(k_add_u32_i, unsigned int), CASE(k_add_u32_d, unsigned int), CASE(k_lshl_b32_i, unsigned int),
+      CASE(k_and_b32_i, unsigned int), CASE(k_or_b32_i, unsigned int), CASE(k_xor_b32_i, unsigned int), CASE(k_lshr_b32_i, unsigned int),
+      CASE(k_ashr_i32_i, unsigned int), CASE(k_min_u32_i, unsigned int), CASE(k_max_i32_i, unsigned int), CASE(k_sub_u32_i, unsigned int),
+      CASE(k_mov_b32_i, unsigned int), CASE(k_add3_u32_i, unsigned int), CASE(k_lshl_add_u32_i, unsigned int), CASE(k_and_or_b32_i, unsigned int),
+      CASE(k_bfe_u32_i, unsigned int), CASE(k_cvt_f32_i32_i, unsigned int), CASE(k_cvt_i32_f32_i, float), CASE(k_floor_f32_i, float),
+      CASE(k_rcp_f32_i, float), CASE(k_mov_b64_i, double), CASE(k_cndmask_i, unsigned int), CASE(k_cmp_u32_i, unsigned int),
+      CASE(k_ds_read_b32_d, unsigned int), CASE(k_salu_i, int),
       CASE(k_valu_salu_mix, int), CASE(k_f64_f32_mix, double)};
   unsigned long long *out;
   void *sink;
