@@ -48,7 +48,7 @@ class State(C.Structure):
 
 PLAN_INT_FIELDS = ('planner', 'gaze', 'nu', 'n_sample', 'n_ts', 'max_itr', 'traj_cap', 'node_cap', 'hash_cap', 'n_yaw',
                    'pw_nleaf', 'pw_nprog', 'tobs_len', 'pw_ntree')
-PLAN_F64_FIELDS = ('horizon', 'vmax', 'safe_dist', 'goal_tol', 'agent_radius', 'half_fov', 'yaw_rate_max')
+PLAN_F64_FIELDS = ('horizon', 'vmax', 'safe_dist', 'goal_tol', 'agent_radius', 'half_fov', 'yaw_rate_max', 'vmax_sq', 'goal_sq')
 PLAN_TABLES = ('u_space', 'sample_t', 'traj_t', 'yaw_space', 'tobs_tab', 'pw_leaf', 'pw_prog', 'pw_tree', 'pw_rowleaf', 'trk_radius0')
 PLAN_STATE = ('traj', 'traj_hdr', 'trk_radius', 'trk_prev', 'trk_lim', 'seen_step', 'nodes', 'hash', 'launch_args', 'plan_stat')
 LAUNCH_ARGS_BYTES = 2048

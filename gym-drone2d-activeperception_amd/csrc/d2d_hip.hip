@@ -1776,6 +1776,7 @@ __host__ __device__ inline int closed_wave_bytes(const d2d_cfg &c, const d2d_pla
   return (b + 15) & ~15;
 }
 
+
 // function arguments arrive in VGPRs; these are wave-uniform by construction, say so -- and say that the bundle lives in
 // device memory nobody writes during the launch (constant address space): its fields then come through scalar loads
 // instead of per-lane `flat_load`s

@@ -297,8 +297,8 @@ __device__ int plan_search(const d2d_cfg &c, const d2d_state &s, const d2d_plan 
   }
   for (int i = lane; i < 2 * p.n_sample; i += WAVE) S.st[i] = p.sample_t[i];
   {
-    unsigned int *lh32 = (unsigned int *)S.lh;
-    for (int i = lane; i < LH_N / 2; i += WAVE) lh32[i] = 0u;
+    uint4 *lh128 = (uint4 *)S.lh;  // (16-byte aligned: plan_carve)
+    for (int i = lane; i < LH_N / 8; i += WAVE) lh128[i] = make_uint4(0u, 0u, 0u, 0u);
   }
   // integer probes for the collision samples: grid scale 10, map below 81920 px, integer safety distance (the samples are
   // integer-valued: np.around)
@@ -316,22 +316,58 @@ __device__ int plan_search(const d2d_cfg &c, const d2d_state &s, const d2d_plan 
                     c.H_px == 10.0 * (double)c.H && safe_i == 10 * kcell && 2 * kcell <= min(c.W, c.H);
   if (rows) {
     int olo = 0, ohi = 0;  // lane i: the occupancy bits of grid row i (bit j = explored map holds OCCUPIED at (i, j))
-    const int jc = min(lane, c.H - 1);
-    for (int i0 = 0; i0 < c.W; i0 += 8) {
-      unsigned char v[8];
+    unsigned long long *orow = (unsigned long long *)S.rk;
+    const int nb = c.W * c.H;
+    if (c.grid_tile == 0 && (nb & 3) == 0 && (((size_t)dm) & 3) == 0) {
+      // row-major map, dword aligned: ten dwords per lane in flight (one round trip for a 50 x 50 map), the few OCCUPIED bytes found by
+      // an exact zero-byte test on x ^ 0x01010101 and ORed into their rows in LDS -- most dwords hold none and cost six instructions
+      orow[lane] = 0ull;
+      const unsigned int *src = (const unsigned int *)dm;
+      const FastDiv fdh(c.H);
+      for (int d0 = 0; d0 < nb / 4; d0 += 10 * WAVE) {
+        unsigned int x[10];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = dm[grid_ix(c, min(i0 + u, c.W - 1), jc)];
+        for (int u = 0; u < 10; ++u) {
+          const int idx = d0 + u * WAVE + lane;
+          x[u] = src[min(idx, nb / 4 - 1)];
+        }
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        if (i0 + u < c.W) {  // wave-uniform
-          const unsigned long long m = __ballot(lane < c.H && v[u] == D2D_OCCUPIED);
-          olo = lane == i0 + u ? (int)(unsigned int)m : olo;
-          ohi = lane == i0 + u ? (int)(unsigned int)(m >> 32) : ohi;
+        for (int u = 0; u < 10; ++u) {
+          const int idx = d0 + u * WAVE + lane;
+          const unsigned int y = x[u] ^ 0x01010101u;  // a zero byte where the cell holds OCCUPIED (1)
+          unsigned int z = ~(((y & 0x7f7f7f7fu) + 0x7f7f7f7fu) | y | 0x7f7f7f7fu);  // bit 7 of exactly the zero bytes
+          if (idx >= nb / 4) z = 0u;
+          while (z) {
+            const int b = (__ffs((int)z) - 1) >> 3;
+            z &= z - 1u;
+            int i, j;
+            fdh.divmod_big(4 * idx + b, i, j);
+            atomicOr(&orow[i], 1ull << j);
+          }
+        }
+      }
+      wave_sync_lds();
+      const unsigned long long o = orow[lane];
+      olo = (int)(unsigned int)o;
+      ohi = (int)(unsigned int)(o >> 32);
+      wave_sync_lds();
+    } else {
+      const int jc = min(lane, c.H - 1);
+      for (int i0 = 0; i0 < c.W; i0 += 8) {
+        unsigned char v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = dm[grid_ix(c, min(i0 + u, c.W - 1), jc)];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          if (i0 + u < c.W) {  // wave-uniform
+            const unsigned long long m = __ballot(lane < c.H && v[u] == D2D_OCCUPIED);
+            olo = lane == i0 + u ? (int)(unsigned int)m : olo;
+            ohi = lane == i0 + u ? (int)(unsigned int)(m >> 32) : ohi;
+          }
         }
       }
     }
     const unsigned long long occ = ((unsigned long long)(unsigned int)ohi << 32) | (unsigned int)olo;
-    unsigned long long *orow = (unsigned long long *)S.rk;
     orow[lane] = occ;
     wave_sync_lds();
     const unsigned long long up = orow[max(lane - kcell, 0)], dn = orow[min(lane + kcell, WAVE - 1)];
@@ -345,8 +381,9 @@ __device__ int plan_search(const d2d_cfg &c, const d2d_state &s, const d2d_plan 
   const double kInf = __longlong_as_double(0x7ff0000000000000ll);
   // norm(v_end) < vmax  <=>  v.v <= (largest s with sqrt(s) < vmax)  -- sq_threshold of the double below vmax;
   // norm(p - target) <= goal_tol  <=>  d.d <= sq_threshold(goal_tol): no square root per expansion
-  const double vmax2 = p.vmax > 0.0 ? sq_threshold(__longlong_as_double(__double_as_longlong(p.vmax) - 1)) : -1.0;
-  const double goal2 = sq_threshold(p.goal_tol);
+  // (the host hands both over, d2d_plan.vmax_sq / goal_sq; a caller that leaves them 0 pays four square roots per search)
+  const double vmax2 = p.vmax_sq != 0.0 ? p.vmax_sq : (p.vmax > 0.0 ? sq_threshold(__longlong_as_double(__double_as_longlong(p.vmax) - 1)) : -1.0);
+  const double goal2 = p.goal_sq != 0.0 ? p.goal_sq : sq_threshold(p.goal_tol);
   wave_sync_lds();
   if (lane == 0) {
     const double x = dr[D2D_D_X], y = dr[D2D_D_Y], vx = dr[D2D_D_VX], vy = dr[D2D_D_VY];
@@ -372,7 +409,7 @@ __device__ int plan_search(const d2d_cfg &c, const d2d_state &s, const d2d_plan 
   bool nodup;
   {
     double dmin = 1e300;
-    for (int i = lane; i + 1 < p.nu; i += WAVE) dmin = fmin(dmin, p.u_space[i + 1] - p.u_space[i]);
+    for (int i = lane; i + 1 < p.nu; i += WAVE) dmin = fmin(dmin, S.us[i + 1] - S.us[i]);  // (staged above, behind a hand-off)
     for (int o = 32; o > 0; o >>= 1) dmin = fmin(dmin, shfl_f64(dmin, (lane ^ o)));
     nodup = H * dmin > 1.0 + 1e-6;
   }

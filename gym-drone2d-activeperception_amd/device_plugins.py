@@ -150,6 +150,19 @@ def pairwise_sum_host(a, leaves, prog):
 # ---------------------------------------------------------------------------------------------------
 # tables
 # ---------------------------------------------------------------------------------------------------
+def sq_threshold(L):
+    """The largest double s with sqrt(s) <= L (math.sqrt is IEEE's correctly rounded square root, hence monotone): `norm(d) <= L` with
+    numpy's norm = sqrt(d.d) is exactly `d.d <= sq_threshold(L)`."""
+    if not L >= 0.0:
+        return -1.0
+    t = L * L
+    while math.sqrt(t) > L:
+        t = math.nextafter(t, -math.inf)
+    while math.sqrt(math.nextafter(t, math.inf)) <= L:
+        t = math.nextafter(t, math.inf)
+    return t
+
+
 def build_tables(params, cfg, need_acos=True):
     """Scalars + numpy tables of `d2d_plan`, each computed as the reference computes it.  `need_acos`: the arccos decision
     window of the Oxford stage (view ranges it cannot describe only matter when that stage runs)."""
@@ -202,6 +215,8 @@ def build_tables(params, cfg, need_acos=True):
               pw_nleaf=len(leaves), pw_nprog=len(prog), tobs_len=n_calls, pw_ntree=len(t['pw_tree']),
               horizon=float(horizon), vmax=float(p.drone_max_speed), safe_dist=float(p.drone_radius + 10),
               goal_tol=10.0, agent_radius=float(p.agent_radius), half_fov=half, yaw_rate_max=float(w),
+              vmax_sq=sq_threshold(math.nextafter(float(p.drone_max_speed), -math.inf)) if p.drone_max_speed > 0 else -1.0,   # norm < vmax
+              goal_sq=sq_threshold(10.0),
               acos_key_lo=key_lo, acos_mask=mask)
     return sc, t
 

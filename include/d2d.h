@@ -242,6 +242,9 @@ typedef struct d2d_plan {
   double agent_radius; /* params.agent_radius: KalmanFilter.radius after an archive (utils.py:184) */
   double half_fov;     /* math.radians(drone_view_range / 2) (yaw_planner.py:72) */
   double yaw_rate_max; /* drone_max_yaw_speed (yaw_planner.py:127) */
+  double vmax_sq;      /* the largest double s with sqrt(s) < vmax: `norm(v) < vmax` (traj_planner.py:172) as `v.v <= vmax_sq` without a
+                          square root per primitive (sqrt is correctly rounded, hence monotone); 0 = the library finds it at every search */
+  double goal_sq;      /* the largest double s with sqrt(s) <= goal_tol (traj_planner.py:158), same use; 0 = as above (ABI 7) */
   int64_t acos_key_lo;
   uint64_t acos_mask;
   /* ---- constant tables (read only) ---- */

@@ -45,7 +45,7 @@ def test_header_constants_match_ctypes_mirror(pkg):
         if m:
             names.append(m.group(2))
     assert names == [f[0] for f in A.Plan._fields_]
-    assert C.sizeof(A.Plan) == 14 * 4 + 7 * 8 + 2 * 8 + (len(A.PLAN_TABLES) + len(A.PLAN_STATE)) * 8 and len(A.PLAN_INT_FIELDS) == 14
+    assert C.sizeof(A.Plan) == 14 * 4 + 9 * 8 + 2 * 8 + (len(A.PLAN_TABLES) + len(A.PLAN_STATE)) * 8 and len(A.PLAN_INT_FIELDS) == 14
     for name, val in (('D2D_NODE_F', A.NODE_F), ('D2D_PLAN_PRIMITIVE', A.PLAN_PRIMITIVE), ('D2D_GAZE_OXFORD', A.GAZE_OXFORD),
                       ('D2D_LAUNCH_ARGS_BYTES', A.LAUNCH_ARGS_BYTES)):
         assert int(defs[name]) == val, name
