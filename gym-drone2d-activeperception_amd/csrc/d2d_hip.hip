@@ -54,6 +54,25 @@
 #define D2D_MIN_WAVES 4  // waves per SIMD the register allocator must leave room for (4096 envs = 4 waves per SIMD)
 #endif
 
+#ifdef D2D_CHAIN_PROF
+// Diagnostic build only (tools/chain_prof.py): shader clocks per phase of the persistent loop, [B][8]: gaze, perceive, planner's
+// every-step part, search, act, then the sections of the gaze stage (GZ), summed over the steps of a launch; [B][16]
+__device__ unsigned long long *d2d_phase_buf = nullptr;
+#define D2D_PHASE_ADD(idx, t0)                                                                                        \
+  do {                                                                                                                \
+    if (d2d_phase_buf && (threadIdx.x & (WAVE - 1)) == 0) d2d_phase_buf[(size_t)e * 16 + (idx)] += __builtin_amdgcn_s_memtime() - (t0); \
+  } while (0)
+// sections of the gaze stage (drains the memory counters: shares, not absolute times)
+#define GZ(idx)                                                                                  \
+  do {                                                                                           \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                  \
+    const unsigned long long gz_now = __builtin_amdgcn_s_memtime();                              \
+    if (d2d_phase_buf && lane == 0) d2d_phase_buf[(size_t)e * 16 + 5 + (idx)] += gz_now - gz_t;  \
+    gz_t = gz_now;                                                                               \
+  } while (0)
+#else
+#define GZ(idx) do { } while (0)
+#endif
 #ifdef D2D_STAMPS
 // Diagnostic build only (tools/stage_stamps.py): per-env shader-clock stamps at stage boundaries.
 __device__ unsigned long long *d2d_stamp_buf = nullptr;
@@ -1363,7 +1382,9 @@ __device__ __forceinline__ void run_env(const d2d_cfg &c, const d2d_state &s, in
   unsigned char *__restrict__ dm = s.dmap + (size_t)e * gbytes;
 
   // ---------------- batch 1 ----------------
-  const bool gt_staged = FULL && (do_ray || do_dyn);  // the five collision probes alone read global memory directly
+  // the five collision probes alone read global memory directly (staging the grid for them too -- one round trip fewer in the act
+  // phase -- measured: no gain, 2.5 KB more traffic per env-step)
+  const bool gt_staged = FULL && (do_ray || do_dyn);
   if constexpr (FULL) {
     if (gt_staged) grid_stage(gt, L.gtw, W * H, lane);
     if (do_obs) grid_stage(dm, L.dmt, W * H, lane);
@@ -1833,8 +1854,15 @@ __device__ __attribute__((noinline)) void ph_gaze_stages(const ClosedArgs *ap, i
   char *base = d2d_lds + __builtin_amdgcn_readfirstlane(lds_off_);
   d2d_cfg c = a->c;
   if (!spec_generic(SPEC)) spec_default_apply(c);
+#ifdef D2D_CHAIN_PROF
+  const unsigned long long pp0 = __builtin_amdgcn_s_memtime();
+#endif
   gaze_env(c, a->s, a->p, a->init, a->on_done == D2D_DONE_RESET, e, lane, base);
   wave_sync_global();
+#ifdef D2D_CHAIN_PROF
+  D2D_PHASE_ADD(0, pp0);
+  const unsigned long long pp1 = __builtin_amdgcn_s_memtime();
+#endif
   const int wpb = (SPEC == 1 || SPEC == 2) ? WAVES_PER_BLOCK : (int)(blockDim.x / WAVE);
   const Geom g = make_geom(c, wpb, spec_ncap(SPEC), spec_full(SPEC));
   const LdsView L = carve(base, g, c.L);
@@ -1845,6 +1873,9 @@ __device__ __attribute__((noinline)) void ph_gaze_stages(const ClosedArgs *ap, i
   run_env<spec_full(SPEC), spec_wide(SPEC), spec_cone(SPEC), spec_tiled(SPEC)>(c, a->s, e, lane, STAGES, g, L, a->s.action[e], r, noise_off);
   if (lane == 0) store_regs(a->s, e, r);
   wave_sync_global();
+#ifdef D2D_CHAIN_PROF
+  D2D_PHASE_ADD(1, pp1);
+#endif
 }
 
 template <int SPEC, uint32_t STAGES>
@@ -1893,7 +1924,14 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK, D2D_MIN_WAVES) void k_closed
       // and levels 1-2 measure the same, level 3 -- the search's own -- less.)
       if (nsearch * 32 > t + 16) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);
       ph_gaze_stages<SPEC, D2D_ST_PERCEIVE>(a, e, off, t);
-      if (__builtin_amdgcn_readfirstlane(ph_plan_quick<SPEC>(a, e, off))) {
+#ifdef D2D_CHAIN_PROF
+      const unsigned long long q0 = __builtin_amdgcn_s_memtime();
+#endif
+      const int need = __builtin_amdgcn_readfirstlane(ph_plan_quick<SPEC>(a, e, off));
+#ifdef D2D_CHAIN_PROF
+      D2D_PHASE_ADD(2, q0);
+#endif
+      if (need) {
 #ifdef D2D_CHAIN_PROF
         const unsigned long long s0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -1901,9 +1939,16 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK, D2D_MIN_WAVES) void k_closed
         nsearch += 1;
 #ifdef D2D_CHAIN_PROF
         cps += __builtin_amdgcn_s_memtime() - s0;
+        D2D_PHASE_ADD(3, s0);
 #endif
       }
+#ifdef D2D_CHAIN_PROF
+      const unsigned long long a0 = __builtin_amdgcn_s_memtime();
+#endif
       ph_stages<SPEC, D2D_ST_ACT>(a, e, off);
+#ifdef D2D_CHAIN_PROF
+      D2D_PHASE_ADD(4, a0);
+#endif
     } else {
       ph_gaze_stages<SPEC, D2D_ST_ALL>(a, e, off, t);
     }
@@ -2134,6 +2179,12 @@ extern "C" {
 #ifdef D2D_STAMPS
 int d2d_debug_set_stamps(unsigned long long *buf) {
   return hipMemcpyToSymbol(HIP_SYMBOL(d2d_stamp_buf), &buf, sizeof(buf)) == hipSuccess ? 0 : -3;
+}
+#endif
+
+#ifdef D2D_CHAIN_PROF
+int d2d_debug_set_phase_buf(unsigned long long *buf) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(d2d_phase_buf), &buf, sizeof(buf)) == hipSuccess ? 0 : -3;
 }
 #endif
 

@@ -926,10 +926,14 @@ __device__ __forceinline__ bool plan_env_quick(const d2d_cfg &c, const d2d_state
     bool act = false;
     double m0 = 0, m1 = 0, m2 = 0, m3 = 0, rad = 0, lim2 = 0;
     if (k < N) {
+      // one batch of loads: the tracker's mean is fetched whether or not it is active (a second, dependent round trip otherwise)
+      const double *mu = s.kf + ((size_t)e * N + k) * D2D_KF;
+      m0 = mu[0]; m1 = mu[1]; m2 = mu[2]; m3 = mu[3];
       act = s.active[(size_t)e * N + k] != 0;
       const bool prev = p.trk_prev[(size_t)e * N + k] != 0;
       rad = p.trk_radius[(size_t)e * N + k];
-      lim2 = p.trk_lim[(size_t)e * N + k];
+      const double lim_in = p.trk_lim[(size_t)e * N + k];
+      lim2 = lim_in;
       if (prev && !act) {
         rad = p.agent_radius;
         p.trk_radius[(size_t)e * N + k] = rad;
@@ -938,12 +942,8 @@ __device__ __forceinline__ bool plan_env_quick(const d2d_cfg &c, const d2d_state
       // replan_check's `norm(d) <= drone_radius + radius` as `d.d <= lim2`: the threshold (three square roots to find) only
       // changes with the tracker's radius, so it is kept in the plugin state; 0 = not computed for this radius yet
       if (act && !(lim2 > 0.0)) lim2 = sq_threshold(c.drone_radius + rad);
-      if (lim2 != p.trk_lim[(size_t)e * N + k]) p.trk_lim[(size_t)e * N + k] = lim2;
+      if (lim2 != lim_in) p.trk_lim[(size_t)e * N + k] = lim2;
       if (prev != act) p.trk_prev[(size_t)e * N + k] = act ? 1 : 0;
-      if (act) {
-        const double *mu = s.kf + ((size_t)e * N + k) * D2D_KF;
-        m0 = mu[0]; m1 = mu[1]; m2 = mu[2]; m3 = mu[3];
-      }
     }
     const unsigned long long am = __ballot(act);
     if (act) {
@@ -1177,6 +1177,9 @@ __device__ __forceinline__ void gaze_env(const d2d_cfg &c, const d2d_state &s, c
     wave_sync_global();
   }
   if (p.gaze != D2D_GAZE_OXFORD) return;
+#ifdef D2D_CHAIN_PROF
+  unsigned long long gz_t = __builtin_amdgcn_s_memtime();
+#endif
   const GazeGeom g = gaze_geom(c, p);
   double *rew = (double *)base;                                   // [ncell]
   const int nnode = g.nnode;                                      // blocks + their pairwise sums up to the root (sparse: the hot blocks)
@@ -1240,6 +1243,7 @@ __device__ __forceinline__ void gaze_env(const d2d_cfg &c, const d2d_state &s, c
     cone[a].cy = vdir[2 * a];
     cone[a].sy = vdir[2 * a + 1];
   }
+  GZ(0);  // tables, the seven view directions
   // ---- t_i: cells the current pose sees (yaw_planner.py:93-97); only the box around the drone can be seen ----
   // cos / sin of the pre-test sectors (float, with degrees of slack): the drone's own view, and the sector that holds every
   // candidate's view (half_fov + the largest yaw step)
@@ -1274,6 +1278,7 @@ __device__ __forceinline__ void gaze_env(const d2d_cfg &c, const d2d_state &s, c
   if (lane == 0) act[e] = 0.0;
   return;
 #endif
+  GZ(1);  // seen pass
   if (n == 0) {  // :118-119
     if (lane == 0) act[e] = 0.0;
     return;
@@ -1294,6 +1299,7 @@ __device__ __forceinline__ void gaze_env(const d2d_cfg &c, const d2d_state &s, c
     }
   }
   wave_sync_global();  // LDS hand-off of the swept map AND the seen map the lanes wrote above
+  GZ(2);  // swept map + fence
 #if defined(D2D_GAZE_ABL) && D2D_GAZE_ABL == 2
   if (lane == 0) act[e] = 0.0;
   return;
@@ -1352,6 +1358,7 @@ __device__ __forceinline__ void gaze_env(const d2d_cfg &c, const d2d_state &s, c
   if (lane == 0) act[e] = 0.0;
   return;
 #endif
+  GZ(3);  // live-cell compaction
   for (int l0 = 0; l0 < nlive; l0 += 4 * WAVE) {
     // four live cells per lane: their seen-map entries are fetched together, then their table rows, then the arithmetic
     int qq[4], sn[4];
@@ -1450,6 +1457,7 @@ __device__ __forceinline__ void gaze_env(const d2d_cfg &c, const d2d_state &s, c
   // is set.  The eight chains of a block are eight neighbouring lanes: ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) by three
   // shuffles per candidate.  (Block offsets are multiples of 8, so g % 8 == r.)  ~800 instructions instead of the
   // ~2000 of a (candidate, r) mapping whose lanes walk every slot of every block.
+  GZ(4);  // rewards + candidate bits
   const FastDiv fdh(H);
   const unsigned long long hrows = ((unsigned long long)(unsigned int)rng[1] << 32) | (unsigned int)rng[0];
   const unsigned long long hcols = ((unsigned long long)(unsigned int)rng[3] << 32) | (unsigned int)rng[2];
@@ -1517,6 +1525,7 @@ __device__ __forceinline__ void gaze_env(const d2d_cfg &c, const d2d_state &s, c
     nhl += __popcll(hm);
   }
   wave_sync_lds();
+  GZ(5);  // hot blocks
   const int nchain = 8 * nhl;
   const int per_row = (min(jhi - jlo, g.bbn) + 7 + 7) >> 3;  // cells of one residue among the columns with a non-zero term, at most
   const int max_span = 127 / H + 2;      // grid rows a block of <= 128 cells can touch
@@ -1579,6 +1588,7 @@ __device__ __forceinline__ void gaze_env(const d2d_cfg &c, const d2d_state &s, c
   if (p.n_yaw <= 6) walk(std::integral_constant<int, 6>{});
   else walk(std::integral_constant<int, 7>{});
   wave_sync_lds();
+  GZ(6);  // pairwise block sums
 #if defined(D2D_GAZE_ABL) && D2D_GAZE_ABL == 5
   if (lane == 0) act[e] = 0.0;
   return;
@@ -1667,6 +1677,7 @@ __device__ __forceinline__ void gaze_env(const d2d_cfg &c, const d2d_state &s, c
     }
   }
   if (lane == 0) act[e] = p.yaw_space[best] / p.yaw_rate_max;  // :127
+  GZ(7);  // tree + argmax
 }
 
 // mode: 0 plain, 1 reset the envs that are done first, 2 leave the envs that are done untouched

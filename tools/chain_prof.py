@@ -18,7 +18,12 @@ p = pkg.Params(planner='Primitive', gaze_method='Oxford', agent_number=10, agent
 env = vec_env.VecDrone2DEnv(p, B, planner='Primitive', device_plugins=True, gaze='Oxford')
 env.closed_loop(300, auto_reset=True)
 torch.cuda.synchronize()
+import ctypes as C
+phase = torch.zeros(B, 16, dtype=torch.int64, device='cuda')
+env.backend.lib.d2d_debug_set_phase_buf.argtypes = [C.c_void_p]
+assert env.backend.lib.d2d_debug_set_phase_buf(phase.data_ptr()) == 0
 for rep in range(2):
+    phase.zero_()
     s0 = env.plugins.t['plan_stat'][:, 0].clone()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
@@ -37,6 +42,12 @@ for rep in range(2):
     top = np.argsort(chain)[-8:][::-1]
     for e in top:
         print(f'  env {e:5d}: chain {chain[e] / clk / 1e3:7.2f} ms, searches {ns[e]:4d}, search time {srch[e] / clk / 1e3:7.2f} ms, per step w/o search {(chain[e] - srch[e]) / clk / STEPS:6.1f} us')
+    ph = phase.cpu().numpy().astype(np.float64) / clk / STEPS          # us per step and phase
+    names = ['gaze', 'perceive', 'planner every-step part', 'search', 'act']
+    print('per-step time by phase (us), mean over envs / the 16 longest chains: ' + ', '.join(
+        f'{n} {ph[:, i].mean():.1f} / {ph[np.argsort(chain)[-16:], i].mean():.1f}' for i, n in enumerate(names)))
+    gz = ['tables + directions', 'seen pass', 'swept map + fence', 'live cells', 'rewards + bits', 'hot blocks', 'block sums', 'tree + argmax']
+    print('gaze sections (us per step, stamped: shares): ' + ', '.join(f'{n} {ph[:, 5 + i].mean():.2f}' for i, n in enumerate(gz)))
     nos = (chain - srch) / clk / STEPS
     print('per-step time without searches (us): mean %.1f  p10 %.1f  p90 %.1f' % (nos.mean(), pct(nos, 10), pct(nos, 90)))
     print('per-search time (us): mean %.1f' % (srch.sum() / max(ns.sum(), 1) / clk))
