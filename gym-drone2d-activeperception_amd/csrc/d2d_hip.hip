@@ -224,7 +224,10 @@ __host__ __device__ inline Geom make_geom(const d2d_cfg &c, int wpb, int ncap_fi
   const int base = (32 + 4 + 12 + 2) * g.ncap + 36 * g.ccap + 4 * g.bmw + 4 * g.wdw + 4 * g.ldw;
   // tracker state staged in LDS only while the wave stays within the 10 KB that keep 16 waves on a CU: beyond that the
   // occupancy it would cost is worth more than the staging (the trackers then come straight from global memory)
-  g.kf_lds = (c.kf_enabled && ((base + 160 * g.ncap + 15) & ~15) <= 10240) ? 1 : 0;
+#ifndef D2D_LDS_WAVE_BUDGET
+#define D2D_LDS_WAVE_BUDGET 10240
+#endif
+  g.kf_lds = (c.kf_enabled && ((base + 160 * g.ncap + 15) & ~15) <= D2D_LDS_WAVE_BUDGET) ? 1 : 0;
   (void)wpb;
   g.wave_bytes = (base + (g.kf_lds ? 160 * g.ncap : 0) + 15) & ~15;
   return g;
@@ -1278,6 +1281,123 @@ __device__ __forceinline__ void st_tracker(const d2d_cfg &c, const d2d_state &s,
   }
 }
 
+// The same stage with lane = ONE ELEMENT of one tracker's state (mu[4], Sigma[16]: 20 lanes per tracker, three trackers per pass):
+// the kernels for few agents (SPEC 1, 2), where one to three trackers have anything to do in a step.  With a lane per tracker the
+// stage keeps a whole filter in registers -- 16 + 8 + 8 doubles: the register peak of the kernel (111 VGPRs with it, 82 without)
+// -- and issues a filter's ~170 instructions for one active lane.  Here every lane forms its own element, in two steps through
+// LDS: the predicted element (utils.py:225-240), then -- after the archive test, which every lane of the tracker evaluates on the
+// same predicted values -- the updated one (:249-260).  Each element is the expression the sequential code evaluates for it, operand
+// for operand (F and H are 0 / 1 / 0.1: the dense products collapse without changing a rounding), so the state stays bit-identical.
+template <bool KF_LDS>
+__device__ __forceinline__ void st_tracker_elem(const d2d_cfg &c, const d2d_state &s, int e, int lane, const Geom &g,
+                                                const LdsView &L, EnvRegs &r, size_t noise_off) {
+  const int N = c.N;
+  if (!c.kf_enabled) {
+    for (int k = lane; k < N; k += WAVE)
+      if (L.hit[k] != 0 && L.act[k] == 0) s.active[(size_t)e * N + k] = 1;
+    return;
+  }
+  // the trackers with anything to do (active, or hit this step), in index order
+  short *list = (short *)L.cidx;   // [<= 2 * ccap] (nothing reads the candidate planes after the raycast)
+  double *pbuf = L.cx;             // [3][20] predicted elements of the three trackers of a pass (cx .. crr: 32 * ccap bytes >= 512)
+  int nwork = 0;
+  for (int k0 = 0; k0 < N; k0 += WAVE) {
+    const int k = k0 + lane;
+    const bool need = k < N && (L.act[k] != 0 || L.hit[k] != 0);
+    const unsigned long long m = __ballot(need);
+    if (need) list[nwork + __popcll(m & ((1ull << lane) - 1ull))] = (short)k;
+    nwork += __popcll(m);
+  }
+  if (nwork == 0) return;
+  wave_sync_lds();
+  const int slot = lane >= 40 ? 2 : (lane >= 20 ? 1 : 0), idx = lane - 20 * slot;  // lanes 60..63 idle
+  const bool is_mu = idx < 4;
+  const int ei = is_mu ? idx : (idx - 4) >> 2, ej = is_mu ? 0 : (idx - 4) & 3;       // mu[ei] or Sigma[ei][ej]
+  const double qn = (c.sigma != 0.0) ? 0.1 : 0.001;
+  const double init_el = is_mu ? 0.0 : (ei != ej ? 0.0 : (ei < 2 ? 1.0 : 10.0));    // KalmanFilter.__init__: mu 0, Sigma diag(1, 1, 10, 10)
+  int arch_n = 0, arch_ts = 0;
+  for (int q0 = 0; q0 < nwork; q0 += 3) {
+    const int q = q0 + slot;
+    const bool on = lane < 60 && q < nwork;
+    const int k = on ? (int)list[q] : (int)list[q0];
+    const bool has_z = L.hit[k] != 0, act = L.act[k] != 0;
+    double *__restrict__ gk = s.kf + ((size_t)e * N + k) * D2D_KF;
+    auto old = [&](int el) -> double { return KF_LDS ? L.kf[k * D2D_KF + el] : gk[el]; };
+    // ---- predict (only meaningful for an active tracker; computed by all, selected below) ----
+    double pe;
+    if (is_mu) {
+      const double m_i = old(ei), m_v = old(ei < 2 ? ei + 2 : ei);
+      pe = ei < 2 ? m_i + 0.1 * m_v : m_i;
+    } else {
+      const int lo_i = ei < 2 ? ei + 2 : ei, hi_j = ej < 2 ? ej + 2 : ej;
+      const double s_ij = old(4 + 4 * ei + ej), s_lj = old(4 + 4 * lo_i + ej), s_ih = old(4 + 4 * ei + hi_j), s_lh = old(4 + 4 * lo_i + hi_j);
+      const double r_ij = ei < 2 ? s_ij + 0.1 * s_lj : s_ij;   // Sigma <- F Sigma: rows 0, 1 += 0.1 * rows 2, 3
+      const double r_ih = ei < 2 ? s_ih + 0.1 * s_lh : s_ih;
+      pe = ej < 2 ? r_ij + r_ih * 0.1 : r_ij;                  // Sigma <- Sigma F^T: columns 0, 1 += columns 2, 3 * 0.1
+      if (ei == ej) pe += qn;                                  // + Q
+    }
+    wave_sync_lds();  // (the previous pass has read its pbuf)
+    if (lane < 60) pbuf[lane] = pe;
+    wave_sync_lds();
+    const double *pb = pbuf + 20 * slot;
+    const double pm0 = pb[0], pm1 = pb[1];
+    const bool archive = act && (pb[4] >= 150.0 || !(c.kf_lo_x < pm0 && pm0 < c.kf_hi_x) || !(c.kf_lo_y < pm1 && pm1 < c.kf_hi_y));
+    const bool reset = archive || !act;   // the state the update (if any) starts from is a fresh filter's
+    auto cur = [&](int el, double fresh) -> double { const double v = pb[el]; return reset ? fresh : v; };
+    // the tracker's own len / flags, by the lane of its element 0
+    const int klen = L.klen[k];
+    int len = act ? klen + 1 : 1;
+    if (archive) len = 1;
+    double zx = L.ax[k], zy = L.ay[k];
+    if (s.noise) {
+      zx = zx + c.sigma * s.noise[noise_off + ((size_t)e * N + k) * 2];
+      zy = zy + c.sigma * s.noise[noise_off + ((size_t)e * N + k) * 2 + 1];
+    }
+    double out;
+    if (!act) {  // first sighting, utils.py:263-273 (has_z holds: the tracker is on the list)
+      out = is_mu ? (idx == 0 ? zx : (idx == 1 ? zy : 0.0)) : init_el;
+    } else if (!has_z) {
+      out = reset ? init_el : pe;
+    } else {  // update, utils.py:249-260 (also runs on the freshly reset filter)
+      const double c00 = cur(4, 1.0), c01 = cur(5, 0.0), c10 = cur(8, 0.0), c11 = cur(9, 1.0);
+      const double a = c.sigma + c00, b = c01, cc = c10, d = c.sigma + c11;
+      const double det = a * d - b * cc;
+      const double idet = 1.0 / det;  // inv(S) through one reciprocal (same in oracle/d2d_oracle.c)
+      const double i00 = d * idet, i01 = -b * idet, i10 = -cc * idet, i11 = a * idet;
+      // the gain's row of this element: K[ei] = Sigma[ei][0..1] inv(S)
+      const double ci0 = cur(4 + 4 * ei, ei == 0 ? 1.0 : 0.0), ci1 = cur(4 + 4 * ei + 1, ei == 1 ? 1.0 : 0.0);
+      const double K0 = ci0 * i00 + ci1 * i10, K1 = ci0 * i01 + ci1 * i11;
+      if (is_mu) {
+        const double cm0 = cur(0, 0.0), cm1 = cur(1, 0.0), cmi = cur(ei, 0.0);
+        const double rx = zx - cm0, ry = zy - cm1;
+        out = cmi + (K0 * rx + K1 * ry);
+      } else {
+        const double s0 = cur(4 + ej, ej == 0 ? 1.0 : 0.0), s1 = cur(8 + ej, ej == 1 ? 1.0 : 0.0);
+        const double cij = cur(idx, init_el);
+        const double ka = ei == 0 ? 1.0 - K0 : 0.0 - K0, kb = ei == 1 ? 1.0 - K1 : 0.0 - K1;   // (I - K H)[ei][0..1]
+        const double t2 = ka * s0 + kb * s1;
+        out = ei < 2 ? t2 : t2 + cij;
+      }
+    }
+    if (on) {
+      gk[idx] = out;
+      if (idx == 0) {
+        const unsigned char nact = archive ? 0 : 1;   // predict() re-initialised the filter (utils.py:238): inactive, even if update() then corrects it
+        if (archive) {
+          arch_n += 1;
+          arch_ts += klen + 1;
+        }
+        s.kf_len[(size_t)e * N + k] = len;
+        s.active[(size_t)e * N + k] = nact;
+        L.act[k] = nact;
+        L.klen[k] = len;
+      }
+    }
+  }
+  r.bufn += wave_sum(arch_n);
+  r.bufts += wave_sum(arch_ts);
+}
+
 // utils.py:764-778 + envs/drone_v2.py:217-235.  `probe_wall`: the lane's batch-2 static probe (lane < 5).
 __device__ __forceinline__ void st_collide(const d2d_cfg &c, const d2d_state &s, int e, int lane, const LdsView &L,
                                            bool probe_wall, EnvRegs &r) {
@@ -1543,8 +1663,13 @@ __device__ __forceinline__ void run_env(const d2d_cfg &c, const d2d_state &s, in
   D2D_STAMP(7);
 #ifndef D2D_ABL_NOTRK
   if (do_trk) {  // two instantiations: a run-time choice between an LDS and a global pointer would become flat loads
-    if (g.kf_lds) st_tracker<true>(c, s, e, lane, g, L, r, noise_off);
-    else st_tracker<false>(c, s, e, lane, g, L, r, noise_off);
+    if constexpr (FULL) {  // few agents: lane = element of a tracker's state
+      if (g.kf_lds) st_tracker_elem<true>(c, s, e, lane, g, L, r, noise_off);
+      else st_tracker_elem<false>(c, s, e, lane, g, L, r, noise_off);
+    } else {
+      if (g.kf_lds) st_tracker<true>(c, s, e, lane, g, L, r, noise_off);
+      else st_tracker<false>(c, s, e, lane, g, L, r, noise_off);
+    }
   }
 #endif
   D2D_STAMP(8);
