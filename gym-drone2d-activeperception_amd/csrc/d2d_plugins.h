@@ -1237,12 +1237,11 @@ __device__ __forceinline__ void gaze_env(const d2d_cfg &c, const d2d_state &s, c
     vdir[2 * lane + 1] = syv;
   }
   wave_sync_lds();
-  ViewCone cone[8];
-#pragma unroll
-  for (int a = 0; a < 8; ++a) {
-    cone[a].cy = vdir[2 * a];
-    cone[a].sy = vdir[2 * a + 1];
-  }
+  // the drone's own direction stays in registers; the candidates' (used once per live cell, below) are read from LDS where they are
+  // used: eight directions in registers were 32 VGPRs live across the stage -- its register peak
+  ViewCone cone7;
+  cone7.cy = vdir[14];
+  cone7.sy = vdir[15];
   GZ(0);  // tables, the seven view directions
   // ---- t_i: cells the current pose sees (yaw_planner.py:93-97); only the box around the drone can be seen ----
   // cos / sin of the pre-test sectors (float, with degrees of slack): the drone's own view, and the sector that holds every
@@ -1256,7 +1255,7 @@ __device__ __forceinline__ void gaze_env(const d2d_cfg &c, const d2d_state &s, c
     CellBox b;
     b.i_lo = bi; b.i_hi = bi + g.bbn - 1; b.j_lo = bj; b.j_hi = bj + g.bbn - 1;
     if (boxes) {
-      const CellBox sb = sector_box(x0, y0, c.depth, inv_scale, cone[7].cy, cone[7].sy, __cosf(w_own), __sinf(w_own));
+      const CellBox sb = sector_box(x0, y0, c.depth, inv_scale, cone7.cy, cone7.sy, __cosf(w_own), __sinf(w_own));
       b.i_lo = max(b.i_lo, sb.i_lo); b.i_hi = min(b.i_hi, sb.i_hi); b.j_lo = max(b.j_lo, sb.j_lo); b.j_hi = min(b.j_hi, sb.j_hi);
     }
     b.i_lo = max(b.i_lo, 0); b.i_hi = min(b.i_hi, W - 1); b.j_lo = max(b.j_lo, 0); b.j_hi = min(b.j_hi, H - 1);
@@ -1269,7 +1268,7 @@ __device__ __forceinline__ void gaze_env(const d2d_cfg &c, const d2d_state &s, c
         fds.divmod(q, r, cc);
         const int i = b.i_lo + r, j = b.j_lo + cc;
         if (q < nsub) {
-          if (view_cell(p, depth2, quick, x0, y0, cone[7], (double)i * c.scale, (double)j * c.scale)) seen[i * H + j] = call;
+          if (view_cell(p, depth2, quick, x0, y0, cone7, (double)i * c.scale, (double)j * c.scale)) seen[i * H + j] = call;
         }
       }
     }
@@ -1322,7 +1321,7 @@ __device__ __forceinline__ void gaze_env(const d2d_cfg &c, const d2d_state &s, c
     CellBox b;
     b.i_lo = bi; b.i_hi = bi + g.bbn - 1; b.j_lo = bj; b.j_hi = bj + g.bbn - 1;
     if (boxes) {
-      const CellBox sb = sector_box(hx, hy, c.depth, inv_scale, cone[7].cy, cone[7].sy, __cosf(w_all), __sinf(w_all));
+      const CellBox sb = sector_box(hx, hy, c.depth, inv_scale, cone7.cy, cone7.sy, __cosf(w_all), __sinf(w_all));
       b.i_lo = max(b.i_lo, sb.i_lo); b.i_hi = min(b.i_hi, sb.i_hi); b.j_lo = max(b.j_lo, sb.j_lo); b.j_hi = min(b.j_hi, sb.j_hi);
     }
     b.i_lo = max(b.i_lo, 0); b.i_hi = min(b.i_hi, W - 1); b.j_lo = max(b.j_lo, 0); b.j_hi = min(b.j_hi, H - 1);
@@ -1338,7 +1337,7 @@ __device__ __forceinline__ void gaze_env(const d2d_cfg &c, const d2d_state &s, c
       if (qs < nsub) {
         const double ca = hx - (double)i * c.scale, cb = hy - (double)j * c.scale;
         const double d2 = ca * ca + cb * cb;
-        const double dm = (-ca) * cone[7].cy + (-cb) * cone[7].sy;
+        const double dm = (-ca) * cone7.cy + (-cb) * cone7.sy;
         const bool sector = (wide2 <= 0.0) | (d2 <= 0.0) | ((dm > 0.0) & (dm * dm >= wide2 * d2));
         live = (d2 <= depth2) & sector;
       }
@@ -1408,7 +1407,7 @@ __device__ __forceinline__ void gaze_env(const d2d_cfg &c, const d2d_state &s, c
 #pragma unroll
           for (int a = 0; a < 7; ++a) {
             if (a < p.n_yaw) {
-              const double dot = dxv * cone[a].cy + dyv * cone[a].sy;
+              const double dot = dxv * vdir[2 * a] + dyv * vdir[2 * a + 1];
               const double lhs = dot * dot;
               const bool inside = (quick > 0.0) & (dot > 0.0) & (lhs > hi) & (lhs < top);
               const bool outside = (quick > 0.0) & ((dot <= 0.0) | (lhs < lo));
