@@ -1310,7 +1310,9 @@ __device__ __forceinline__ void st_tracker_elem(const d2d_cfg &c, const d2d_stat
   }
   if (nwork == 0) return;
   wave_sync_lds();
-  const int slot = lane >= 40 ? 2 : (lane >= 20 ? 1 : 0), idx = lane - 20 * slot;  // lanes 60..63 idle
+  // lanes 60..63 are idle: they mirror element 0 of the third tracker (an element index of 20..23 would read past the tracker's
+  // record -- past the END of the kf buffer for the last tracker of the last env: a fault when that buffer ends on a page boundary)
+  const int slot = lane >= 40 ? 2 : (lane >= 20 ? 1 : 0), idx = lane < 60 ? lane - 20 * slot : 0;
   const bool is_mu = idx < 4;
   const int ei = is_mu ? idx : (idx - 4) >> 2, ej = is_mu ? 0 : (idx - 4) & 3;       // mu[ei] or Sigma[ei][ej]
   const double qn = (c.sigma != 0.0) ? 0.1 : 0.001;

@@ -453,3 +453,32 @@ def test_gathered_tracker_filters_with_many_agents(pkg, hip, oracle):
         most = max(most, int(ref.state.active.sum(1).max()))
         archived = int(ref.state.counters[:, A.C_BUF_N].sum())
     assert most >= 12 and archived > 0, (most, archived)
+
+
+def test_tracker_state_buffer_ending_on_a_page_boundary(pkg, hip):
+    """4096 envs x 32 agents: the tracker state `kf` is 4096 * 32 * 160 B = exactly ten 2 MiB pages, and 32 agents take the kernel
+    that reads tracker state from global memory with a lane per element (st_tracker_elem<false>).  Round 3's first version let
+    its four idle lanes read elements 20..23 of a record: past the end of the buffer for the last tracker of the last env -- a GPU
+    memory fault at exactly such sizes (found by the config 4 profile run: 32768 * 24 * 160 B = sixty pages).  The batch must run
+    and equal the 4-env run of its worlds."""
+    from drone2d_amd import vec_env
+    p = pkg.Params(planner='NoMove', agent_number=32, agent_radius=8, agent_max_speed=30, map_id=70)
+    worlds = vec_env.build_worlds(p, 4)
+    B = 4096
+    big = vec_env.VecDrone2DEnv(p, B, backend=hip, worlds=[worlds[i % 4] for i in range(B)])
+    small = vec_env.VecDrone2DEnv(p, 4, backend=hip, worlds=worlds)
+    assert big.state.kf.numel() * 8 % (2 << 20) == 0 and big.cfg.N == 32
+    # drones next to an agent, looking at it: rays hit, trackers start and update
+    ag = small.state.agents
+    pin = torch.stack([ag[:, 0, 3].floor() + 8.0, ag[:, 1, 3].floor() - 40.0], dim=1).clamp(30.0, 470.0)
+    rng = np.random.RandomState(3)
+    for t in range(12):
+        a4 = torch.from_numpy(rng.uniform(-0.3, 0.3, 4))
+        for env, reps in ((big, B // 4), (small, 1)):
+            env.state.drone[:, :2] = pin.repeat(reps, 1).to(env.device)
+            env.step(a4.repeat(reps))
+    big.sync()
+    assert int(small.state.active.sum()) > 0
+    for name in FIELDS:
+        x = big.state.t[name]
+        assert bool((x.view(B // 4, 4, *x.shape[1:]) == small.state.t[name].unsqueeze(0)).all()), name
