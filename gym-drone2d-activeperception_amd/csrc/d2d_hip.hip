@@ -1288,6 +1288,7 @@ __device__ __forceinline__ void st_tracker(const d2d_cfg &c, const d2d_state &s,
 // LDS: the predicted element (utils.py:225-240), then -- after the archive test, which every lane of the tracker evaluates on the
 // same predicted values -- the updated one (:249-260).  Each element is the expression the sequential code evaluates for it, operand
 // for operand (F and H are 0 / 1 / 0.1: the dense products collapse without changing a rounding), so the state stays bit-identical.
+template <bool KF_LDS = true>
 __device__ __forceinline__ void st_tracker_elem(const d2d_cfg &c, const d2d_state &s, int e, int lane, const Geom &g,
                                                 const LdsView &L, EnvRegs &r, size_t noise_off) {
   const int N = c.N;
@@ -1323,7 +1324,7 @@ __device__ __forceinline__ void st_tracker_elem(const d2d_cfg &c, const d2d_stat
     const int k = on ? (int)list[q] : (int)list[q0];
     const bool has_z = L.hit[k] != 0, act = L.act[k] != 0;
     double *__restrict__ gk = s.kf + ((size_t)e * N + k) * D2D_KF;
-    auto old = [&](int el) -> double { return L.kf[k * D2D_KF + el]; };   // the tracker block staged in LDS (Geom.kf_lds)
+    auto old = [&](int el) -> double { return KF_LDS ? L.kf[k * D2D_KF + el] : gk[el]; };   // the tracker block staged in LDS (Geom.kf_lds), or global
     // ---- predict (only meaningful for an active tracker; computed by all, selected below) ----
     double pe;
     if (is_mu) {
@@ -1668,7 +1669,11 @@ __device__ __forceinline__ void run_env(const d2d_cfg &c, const d2d_state &s, in
     // comes from global memory and the lane-per-tracker form fetches every filter in ONE round trip where the per-element form needs
     // one per pass of three trackers (config 4's step: 141 us against 160 us per 32768 envs).
     if (FULL && g.kf_lds) {
-      st_tracker_elem(c, s, e, lane, g, L, r, noise_off);
+      st_tracker_elem<true>(c, s, e, lane, g, L, r, noise_off);
+#ifdef D2D_ELEM_GLOBAL
+    } else if (FULL && g.ncap <= 16) {   // exploration: <= 16 agents with the tracker block left in global memory (5 waves per SIMD)
+      st_tracker_elem<false>(c, s, e, lane, g, L, r, noise_off);
+#endif
     } else {
       if (g.kf_lds) st_tracker<true>(c, s, e, lane, g, L, r, noise_off);
       else st_tracker<false>(c, s, e, lane, g, L, r, noise_off);
