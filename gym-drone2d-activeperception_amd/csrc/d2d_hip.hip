@@ -228,6 +228,10 @@ __host__ __device__ inline Geom make_geom(const d2d_cfg &c, int wpb, int ncap_fi
 #define D2D_LDS_WAVE_BUDGET 10240
 #endif
   g.kf_lds = (c.kf_enabled && ((base + 160 * g.ncap + 15) & ~15) <= D2D_LDS_WAVE_BUDGET) ? 1 : 0;
+  // The whole-grid kernel for <= 16 agents (SPEC 1) runs its trackers with a lane per ELEMENT of a tracker's state (st_tracker_elem):
+  // 83 VGPRs, and with the tracker block left in global memory 6 400 B of LDS per wave -- five waves per SIMD instead of four
+  // (the fused step at 65 536 envs: 239 -> 218 us; the 2 560-byte block was what kept a launch at 16 waves per CU).
+  if (full && g.ncap <= 16) g.kf_lds = 0;
   (void)wpb;
   g.wave_bytes = (base + (g.kf_lds ? 160 * g.ncap : 0) + 15) & ~15;
   return g;
@@ -1282,13 +1286,12 @@ __device__ __forceinline__ void st_tracker(const d2d_cfg &c, const d2d_state &s,
 }
 
 // The same stage with lane = ONE ELEMENT of one tracker's state (mu[4], Sigma[16]: 20 lanes per tracker, three trackers per pass):
-// the kernel for few agents (SPEC 1: the tracker block is staged in LDS), where one to three trackers have anything to do in a step.  With a lane per tracker the
+// the kernel for few agents (SPEC 1), where one to three trackers have anything to do in a step.  With a lane per tracker the
 // stage keeps a whole filter in registers -- 16 + 8 + 8 doubles: the register peak of the kernel (111 VGPRs with it, 82 without)
 // -- and issues a filter's ~170 instructions for one active lane.  Here every lane forms its own element, in two steps through
 // LDS: the predicted element (utils.py:225-240), then -- after the archive test, which every lane of the tracker evaluates on the
 // same predicted values -- the updated one (:249-260).  Each element is the expression the sequential code evaluates for it, operand
 // for operand (F and H are 0 / 1 / 0.1: the dense products collapse without changing a rounding), so the state stays bit-identical.
-template <bool KF_LDS = true>
 __device__ __forceinline__ void st_tracker_elem(const d2d_cfg &c, const d2d_state &s, int e, int lane, const Geom &g,
                                                 const LdsView &L, EnvRegs &r, size_t noise_off) {
   const int N = c.N;
@@ -1324,7 +1327,7 @@ __device__ __forceinline__ void st_tracker_elem(const d2d_cfg &c, const d2d_stat
     const int k = on ? (int)list[q] : (int)list[q0];
     const bool has_z = L.hit[k] != 0, act = L.act[k] != 0;
     double *__restrict__ gk = s.kf + ((size_t)e * N + k) * D2D_KF;
-    auto old = [&](int el) -> double { return KF_LDS ? L.kf[k * D2D_KF + el] : gk[el]; };   // the tracker block staged in LDS (Geom.kf_lds), or global
+    auto old = [&](int el) -> double { return gk[el]; };   // the tracker's record in global memory (four loads per lane in flight)
     // ---- predict (only meaningful for an active tracker; computed by all, selected below) ----
     double pe;
     if (is_mu) {
@@ -1665,15 +1668,11 @@ __device__ __forceinline__ void run_env(const d2d_cfg &c, const d2d_state &s, in
   D2D_STAMP(7);
 #ifndef D2D_ABL_NOTRK
   if (do_trk) {  // two instantiations: a run-time choice between an LDS and a global pointer would become flat loads
-    // few agents with the tracker block staged in LDS (SPEC 1): lane = element of a tracker's state.  With 17 to 40 agents the block
-    // comes from global memory and the lane-per-tracker form fetches every filter in ONE round trip where the per-element form needs
-    // one per pass of three trackers (config 4's step: 141 us against 160 us per 32768 envs).
-    if (FULL && g.kf_lds) {
-      st_tracker_elem<true>(c, s, e, lane, g, L, r, noise_off);
-#ifdef D2D_ELEM_GLOBAL
-    } else if (FULL && g.ncap <= 16) {   // exploration: <= 16 agents with the tracker block left in global memory (5 waves per SIMD)
-      st_tracker_elem<false>(c, s, e, lane, g, L, r, noise_off);
-#endif
+    // <= 16 agents on whole grids (SPEC 1): lane = element of a tracker's state, the record read from global memory.  With 17 to 40
+    // agents the lane-per-tracker form fetches every filter in ONE round trip where the per-element form needs one per pass of three
+    // trackers (config 4's step: 141 us against 160 us per 32768 envs): kept there.
+    if (FULL && g.ncap <= 16) {
+      st_tracker_elem(c, s, e, lane, g, L, r, noise_off);
     } else {
       if (g.kf_lds) st_tracker<true>(c, s, e, lane, g, L, r, noise_off);
       else st_tracker<false>(c, s, e, lane, g, L, r, noise_off);
