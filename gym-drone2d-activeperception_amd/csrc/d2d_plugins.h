@@ -1135,7 +1135,9 @@ __device__ __forceinline__ CellBox sector_box(double cx, double cy, double depth
 // additions) no longer fits the wave's LDS.  Only blocks that hold a non-zero term matter (x + 0.0 == x, every term is >= +0.0) and
 // those lie inside the view box: the SPARSE path finds them by walking numpy's recursion down from the root for the box's cells and
 // adds their sums up the same recursion -- no table of the W x H plan on the device at all (gaze_env).
+#ifndef D2D_GAZE_DENSE_CELLS
 #define D2D_GAZE_DENSE_CELLS 4096
+#endif
 #define D2D_GAZE_HOT 64     // blocks with a non-zero term the sparse path holds (two per box row: a block has >= 64 cells)
 struct GazeGeom {
   int bbn;    // cells per axis of the bounding box of a view disk
