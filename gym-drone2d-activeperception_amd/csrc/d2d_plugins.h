@@ -1138,7 +1138,9 @@ __device__ __forceinline__ CellBox sector_box(double cx, double cy, double depth
 #ifndef D2D_GAZE_DENSE_CELLS
 #define D2D_GAZE_DENSE_CELLS 4096
 #endif
+#ifndef D2D_GAZE_HOT
 #define D2D_GAZE_HOT 64     // blocks with a non-zero term the sparse path holds (two per box row: a block has >= 64 cells)
+#endif
 struct GazeGeom {
   int bbn;    // cells per axis of the bounding box of a view disk
   int ncell;  // bbn * bbn
