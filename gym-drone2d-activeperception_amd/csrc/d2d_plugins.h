@@ -1320,6 +1320,7 @@ __device__ __forceinline__ void gaze_env(const d2d_cfg &c, const d2d_state &s, c
     wide2 = cwd * cwd;
   }
   for (int k = lane; k < (g.ncell + 3) / 4; k += WAVE) ((unsigned int *)cm)[k] = 0u;  // no view bits anywhere else in the box
+  for (int k = lane; k < g.ncell; k += WAVE) rew[k] = 0.0;  // (the sums multiply by the view bit: no stale NaN / inf of another phase)
   int nlive = 0;
   {
     CellBox b;
@@ -1412,9 +1413,11 @@ __device__ __forceinline__ void gaze_env(const d2d_cfg &c, const d2d_state &s, c
           for (int a = 0; a < 7; ++a) {
             if (a < p.n_yaw) {
               const double dot = dxv * vdir[2 * a] + dyv * vdir[2 * a + 1];
-              const double lhs = dot * dot;
-              const bool inside = (quick > 0.0) & (dot > 0.0) & (lhs > hi) & (lhs < top);
-              const bool outside = (quick > 0.0) & ((dot <= 0.0) | (lhs < lo));
+              // dot^2 with dot's sign (hi, lo, top are > 0): `dot > 0 and dot^2 > hi` is `sq > hi`, `dot <= 0 or dot^2 < lo` is `sq < lo`
+              // -- three compares per candidate instead of five; a degenerate lo == 0 only sends dot == 0 to the literal test below
+              const double sq = dot * fabs(dot);
+              const bool inside = (quick > 0.0) & (sq > hi) & (sq < top);
+              const bool outside = (quick > 0.0) & (sq < lo);
               bits |= inside ? (1u << a) : 0u;
               rare |= (inside | outside) ? 0u : (1u << a);
             }
@@ -1561,12 +1564,14 @@ __device__ __forceinline__ void gaze_env(const d2d_cfg &c, const d2d_state &s, c
           const bool on = row_on & (gq < ghi);
           const int q = min(max(rowbase + gq, 0), g.ncell - 1);
           const int bits = on ? (int)cm[q] : 0;
-          const long long rwb = __double_as_longlong(rew[q]);
+          const double rw = rew[q];  // finite everywhere in the box (zeroed above): 0 * rw == +0.0
 #pragma unroll
           for (int a = 0; a < NA; ++a) {
-            // the reward where the candidate's view bit is set, else +0.0 (which changes nothing): the bit as a 64-bit mask
-            const long long msk = (long long)((bits << (31 - a)) >> 31);
-            acc[a] = acc[a] + __longlong_as_double(rwb & msk);
+            // acc + view * reward with view in {0.0, 1.0}: the product is exact (the reward itself, or +0.0 which changes nothing),
+            // so the fused multiply-add rounds once, exactly like the reference's add -- three instructions per candidate
+            // (bit field, and, fma) instead of five (64-bit mask, two ands, add)
+            const double view = __hiloint2double(((bits << (31 - a)) >> 31) & 0x3ff00000, 0);
+            acc[a] = __builtin_fma(rw, view, acc[a]);
           }
         }
       }
@@ -1654,13 +1659,16 @@ __device__ __forceinline__ void gaze_env(const d2d_cfg &c, const d2d_state &s, c
   }
   {
     const int nlev = pwp[0];
-    const int *lstart = pwp + 2, *ops = pwp + 3 + nlev;
+    const int *ops = pwp + 3 + nlev;
+    // the level starts once (lane lv holds level_start[lv]: a lane read per level instead of an LDS round trip), and item k of a
+    // level = (addition k / n_yaw, candidate k % n_yaw): one divisor for all levels, set up outside the loop
+    const int lstart_l = pwp[2 + min(lane, nlev)];
+    const FastDiv fdy(p.n_yaw);
     for (int lv = 0; lv < nlev; ++lv) {
-      const int o0 = lstart[lv], cnt = lstart[lv + 1] - o0;
-      const FastDiv fdc(cnt);
+      const int o0 = __builtin_amdgcn_readlane(lstart_l, lv), cnt = __builtin_amdgcn_readlane(lstart_l, lv + 1) - o0;
       for (int k = lane; k < p.n_yaw * cnt; k += WAVE) {
         int a, ko;
-        fdc.divmod(k, a, ko);
+        fdy.divmod(k, ko, a);
         const int o = o0 + ko;
         const int dst = ops[3 * o], lft = ops[3 * o + 1], rgt = ops[3 * o + 2];
         lsum[a * nnode + dst] = lsum[a * nnode + lft] + lsum[a * nnode + rgt];
