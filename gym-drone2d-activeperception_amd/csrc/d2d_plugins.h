@@ -1175,16 +1175,48 @@ __host__ __device__ inline GazeGeom gaze_geom(const d2d_cfg &c, const d2d_plan &
 // cells fetched before the first is used, the pairwise plan staged in LDS.
 __device__ __forceinline__ void gaze_env(const d2d_cfg &c, const d2d_state &s, const d2d_plan &p, const d2d_state &init,
                                          int auto_reset, int e, int lane, char *base) {
-  if (auto_reset && s.flags[(size_t)e * 4 + D2D_F_DONE] != 0) {
+  // ---- one batch of loads: everything the stage needs that does not hang on another load (the episode flag, the pose, the step
+  //      count, the trajectory header, the table heads, the pairwise plan, the candidates' yaw rates) is requested before the first
+  //      of them is looked at -- one round trip where the straightforward order makes seven dependent ones ----
+  const bool oxford = p.gaze == D2D_GAZE_OXFORD;
+  const GazeGeom g = gaze_geom(c, p);
+  const double *dr = s.drone + (size_t)e * D2D_DF;
+  const int *hdr = p.traj_hdr + (size_t)e * 2;
+  const unsigned char was_done = auto_reset ? s.flags[(size_t)e * 4 + D2D_F_DONE] : (unsigned char)0;
+  double x0 = dr[D2D_D_X], y0 = dr[D2D_D_Y], yaw = dr[D2D_D_YAW];
+  int steps = s.counters[(size_t)e * D2D_CF + D2D_C_STEPS];
+  int head = 0, stored = 0;
+  double ys_l = 0.0, tob_l = 0.0;  // lane a < n_yaw: yaw_space[a]; lane < D2D_TOBS_LDS: its entry of the table of times
+  int pw_l[4] = {0, 0, 0, 0}, pt_l[4] = {0, 0, 0, 0};
+  if (oxford) {
+    head = hdr[0];
+    stored = hdr[1];
+    ys_l = p.yaw_space[min(lane, max(p.n_yaw, 1) - 1)];
+    tob_l = p.tobs_tab[min(lane, p.tobs_len - 1)];
+    if (!g.sparse) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int k = lane + u * WAVE;
+        pw_l[u] = p.pw_leaf[min(k, 4 * p.pw_nleaf - 1)];
+        pt_l[u] = p.pw_tree[min(k, p.pw_ntree - 1)];
+      }
+    }
+  }
+  if (was_done != 0) {
     reset_env(c, s, init, (size_t)e, lane);
     plan_reset_env(c, p, (size_t)e, lane);
     wave_sync_global();
+    x0 = dr[D2D_D_X]; y0 = dr[D2D_D_Y]; yaw = dr[D2D_D_YAW];  // (the fence above: these are fresh loads)
+    steps = s.counters[(size_t)e * D2D_CF + D2D_C_STEPS];
+    if (oxford) {
+      head = hdr[0];
+      stored = hdr[1];
+    }
   }
-  if (p.gaze != D2D_GAZE_OXFORD) return;
+  if (!oxford) return;
 #ifdef D2D_CHAIN_PROF
   unsigned long long gz_t = __builtin_amdgcn_s_memtime();
 #endif
-  const GazeGeom g = gaze_geom(c, p);
   double *rew = (double *)base;                                   // [ncell]
   const int nnode = g.nnode;                                      // blocks + their pairwise sums up to the root (sparse: the hot blocks)
   double *lsum = rew + g.ncell;                                   // [n_yaw][nnode]
@@ -1201,22 +1233,28 @@ __device__ __forceinline__ void gaze_env(const d2d_cfg &c, const d2d_state &s, c
   const double deg2rad = 0x1.1df46a2529d39p-6;                    // math.radians
   const double depth2 = c.depth * c.depth;
   const double inv_scale = 1.0 / c.scale;
-  const double *dr = s.drone + (size_t)e * D2D_DF;
-  const double x0 = dr[D2D_D_X], y0 = dr[D2D_D_Y], yaw = dr[D2D_D_YAW];
-  const int call = s.counters[(size_t)e * D2D_CF + D2D_C_STEPS] + 1;  // one plan() per step, before it
-  const int *hdr = p.traj_hdr + (size_t)e * 2;
-  const int head = hdr[0], n = hdr[1] - hdr[0];
+  const int call = steps + 1;  // one plan() per step, before it
+  const int n = stored - head;
   int *__restrict__ seen = p.seen_step + (size_t)e * W * H;
   double *act = (double *)s.action;
   if (call >= p.tobs_len) {  // stepping past the longest episode (D2D_DONE_CONTINUE): the table ends, the yaw is held
     if (lane == 0) act[e] = 0.0;
     return;
   }
-  // the pairwise plan (a few hundred bytes) into LDS with one coalesced read; used only after several barriers
-  if (lane < D2D_TOBS_LDS) tobl[lane] = p.tobs_tab[min(lane, p.tobs_len - 1)];  // the entries below 1 (reward = the value itself)
+  // the head of the trajectory (the point the candidates look from), requested now, used after the seen pass
+  const double *__restrict__ traj = p.traj + (size_t)e * p.traj_cap * 4;
+  const double2 hxy = *(const double2 *)(traj + (size_t)(n > 0 ? head : 0) * 4);
+  // the table head (the entries below 1: reward = the value itself) and the pairwise plan (a few hundred bytes) into LDS
+  if (lane < D2D_TOBS_LDS) tobl[lane] = tob_l;
   if (!g.sparse) {
-    for (int k = lane; k < 4 * p.pw_nleaf; k += WAVE) pwl[k] = p.pw_leaf[k];
-    for (int k = lane; k < p.pw_ntree; k += WAVE) pwp[k] = p.pw_tree[k];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int k = lane + u * WAVE;
+      if (k < 4 * p.pw_nleaf) pwl[k] = pw_l[u];
+      if (k < p.pw_ntree) pwp[k] = pt_l[u];
+    }
+    for (int k = lane + 4 * WAVE; k < 4 * p.pw_nleaf; k += WAVE) pwl[k] = p.pw_leaf[k];  // (plans beyond 256 entries: none at the
+    for (int k = lane + 4 * WAVE; k < p.pw_ntree; k += WAVE) pwp[k] = p.pw_tree[k];       //  dense path's 4096-cell limit)
   }
   const FastDiv fdb(g.bbn);
   // shortcut of view_cell: only for cones narrower than 180 degrees whose edge is well inside (0, 1); cos(half_fov)
@@ -1233,12 +1271,21 @@ __device__ __forceinline__ void gaze_env(const d2d_cfg &c, const d2d_state &s, c
     double cyv = 0.0, syv = 0.0;
     if (lane < p.n_yaw || lane == 7) {
       // Drone2D.__init__ takes `yaw % 360` for the candidates (utils.py:718); the drone's own yaw already is
-      const double ty = (lane == 7) ? yaw : py_mod360(yaw + p.yaw_space[min(lane, p.n_yaw - 1)] * c.dt);
+      const double ty = (lane == 7) ? yaw : py_mod360(yaw + ys_l * c.dt);
       cyv = d2d_cos(ty * deg2rad);
       syv = -d2d_sin(ty * deg2rad);
     }
     vdir[2 * lane] = cyv;
     vdir[2 * lane + 1] = syv;
+  }
+  // the largest yaw step of a candidate, degrees: a maximum over the lanes that hold the rates (exact in any order)
+  double span_deg;
+  {
+    double m = lane < p.n_yaw ? fabs(ys_l) * c.dt : 0.0;  // (n_yaw <= 7: plan_check)
+    m = fmax(m, row_shl_f64<1>(m));
+    m = fmax(m, row_shl_f64<2>(m));
+    m = fmax(m, row_shl_f64<4>(m));
+    span_deg = readlane_f64(m, 0);
   }
   wave_sync_lds();
   // the drone's own direction stays in registers; the candidates' (used once per live cell, below) are read from LDS where they are
@@ -1250,8 +1297,6 @@ __device__ __forceinline__ void gaze_env(const d2d_cfg &c, const d2d_state &s, c
   // ---- t_i: cells the current pose sees (yaw_planner.py:93-97); only the box around the drone can be seen ----
   // cos / sin of the pre-test sectors (float, with degrees of slack): the drone's own view, and the sector that holds every
   // candidate's view (half_fov + the largest yaw step)
-  double span_deg = 0.0;
-  for (int a = 0; a < p.n_yaw; ++a) span_deg = fmax(span_deg, fabs(p.yaw_space[a]) * c.dt);
   const float w_own = (float)p.half_fov + 2.0f * 0.0174533f, w_all = (float)p.half_fov + ((float)span_deg + 3.0f) * 0.0174533f;
   const bool boxes = w_all < 1.518f && span_deg <= 90.0;  // else: the whole disk's box, no sector pre-test
   {
@@ -1286,8 +1331,7 @@ __device__ __forceinline__ void gaze_env(const d2d_cfg &c, const d2d_state &s, c
     if (lane == 0) act[e] = 0.0;
     return;
   }
-  const double *__restrict__ traj = p.traj + (size_t)e * p.traj_cap * 4;
-  const double hx = traj[(size_t)head * 4], hy = traj[(size_t)head * 4 + 1];
+  const double hx = hxy.x, hy = hxy.y;
   const int bi = (int)floor((hx - c.depth) * inv_scale) - 1, bj = (int)floor((hy - c.depth) * inv_scale) - 1;
   // ---- v_i: the swept map inside the box (last write wins = largest waypoint index), :88-90 ----
   for (int q = lane; q < g.ncell; q += WAVE) swi[q] = -1;
@@ -1468,7 +1512,7 @@ __device__ __forceinline__ void gaze_env(const d2d_cfg &c, const d2d_state &s, c
   const unsigned long long hrows = ((unsigned long long)(unsigned int)rng[1] << 32) | (unsigned int)rng[0];
   const unsigned long long hcols = ((unsigned long long)(unsigned int)rng[3] << 32) | (unsigned int)rng[2];
   if (hrows == 0ull) {  // every sum is 0: `max_reward < 0` never holds, the first candidate stays (yaw_planner.py:116-125)
-    if (lane == 0) act[e] = p.yaw_space[0] / p.yaw_rate_max;
+    if (lane == 0) act[e] = ys_l / p.yaw_rate_max;
     return;
   }
   // rows / columns of the grid that hold a non-zero term (they lie inside the box and inside the map)
@@ -1654,7 +1698,8 @@ __device__ __forceinline__ void gaze_env(const d2d_cfg &c, const d2d_state &s, c
         max_reward = r;
       }
     }
-    if (lane == 0) act[e] = p.yaw_space[best] / p.yaw_rate_max;  // :127
+    const double ys_best = shfl_f64(ys_l, best);  // (every lane takes part: a lane read inside `lane == 0` would find its source masked off)
+    if (lane == 0) act[e] = ys_best / p.yaw_rate_max;  // :127
     return;
   }
   {
@@ -1687,7 +1732,8 @@ __device__ __forceinline__ void gaze_env(const d2d_cfg &c, const d2d_state &s, c
       max_reward = r;
     }
   }
-  if (lane == 0) act[e] = p.yaw_space[best] / p.yaw_rate_max;  // :127
+  const double ys_best = shfl_f64(ys_l, best);
+  if (lane == 0) act[e] = ys_best / p.yaw_rate_max;  // :127
   GZ(7);  // tree + argmax
 }
 
