@@ -439,20 +439,33 @@ struct StepIn {
   bool ok, has_wp;
 };
 
-__device__ __forceinline__ void load_inputs(const d2d_cfg &c, const d2d_state &s, int e, double action, bool control,
-                                            StepIn &in) {
+// The planner's result as it is loaded (load_inputs_raw) and as the control stage reads it (finish_inputs): two steps so that the
+// caller can put everything else it requests from memory between them.
+struct StepInRaw {
+  unsigned char okb, wvb;
+  double w[6];
+  bool use;
+};
+
+__device__ __forceinline__ void load_inputs_raw(const d2d_cfg &c, const d2d_state &s, int e, bool control, StepInRaw &raw) {
+  // No branch around the loads (a branch ends the block: its loads are waited for before it is left, a round trip ahead of
+  // everything requested after it): without a planner the same loads read bytes of the env's own state and are ignored.
+  raw.use = control && c.planner_mode != D2D_PLANNER_NOMOVE;
+  const unsigned char *some_byte = s.flags + (size_t)e * 4;
+  const unsigned char *pok = raw.use ? s.plan_ok + e : some_byte, *pwv = raw.use ? s.wp_valid + e : some_byte;
+  const double *wp = raw.use ? s.wp + (size_t)e * 6 : s.drone + (size_t)e * D2D_DF;  // (D2D_DF >= 6 doubles)
+  raw.okb = *pok;
+  raw.wvb = *pwv;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) raw.w[i] = wp[i];
+}
+
+__device__ __forceinline__ void finish_inputs(const StepInRaw &raw, double action, StepIn &in) {
   in.action = action;
-  in.ok = true;
-  in.has_wp = false;
+  in.ok = raw.use ? raw.okb != 0 : true;
+  in.has_wp = raw.use ? raw.wvb != 0 : false;
 #pragma unroll
-  for (int i = 0; i < 6; ++i) in.wp[i] = 0.0;
-  if (control && c.planner_mode != D2D_PLANNER_NOMOVE) {
-    in.ok = s.plan_ok[e] != 0;
-    in.has_wp = s.wp_valid[e] != 0;
-    const double *wp = s.wp + (size_t)e * 6;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) in.wp[i] = wp[i];
-  }
+  for (int i = 0; i < 6; ++i) in.wp[i] = raw.w[i];  // (read only where has_wp holds)
 }
 
 // envs/drone_v2.py:197-214 with utils.py:733-743, 755-762 (lane-uniform scalar work)
@@ -495,12 +508,13 @@ __device__ __forceinline__ void st_control(const d2d_cfg &c, const StepIn &in, E
 // agents are only staged (a launch without the AGENTS stage).
 // `light`: only the collision test / the trackers follow (no rays, no dynamic grid): positions, radii and tracker flags.
 __device__ __forceinline__ void st_agents(const d2d_cfg &c, const d2d_state &s, int e, int lane, const Geom &g,
-                                          const LdsView &L, double inv_scale, bool move, bool want_trk, bool light = false) {
+                                          const LdsView &L, double inv_scale, bool move, bool want_trk, bool light = false,
+                                          int k_first = 0) {
   const int N = c.N;
   double *__restrict__ ag = s.agents + (size_t)e * D2D_AF * N;
   const int *__restrict__ prev = s.dyn_prev + (size_t)e * N * 3;
   const double cs = 0x1.bb67ae8584cabp-1, sn = 0x1.fffffffffffffp-2;  // cos(pi/6), sin(pi/6)
-  for (int k = lane; k < N; k += WAVE) {
+  for (int k = k_first + lane; k < N; k += WAVE) {
     double px = ag[D2D_A_PX * N + k], py = ag[D2D_A_PY * N + k];
     const double velx = ag[D2D_A_VX * N + k], vely = ag[D2D_A_VY * N + k];
     const double rr = ag[D2D_A_R * N + k];
@@ -1495,7 +1509,8 @@ __device__ __forceinline__ void store_regs(const d2d_state &s, int e, const EnvR
 // WIDE: 64 ray candidates on the mask path (spec_wide).  CONE: candidates culled against the cone of the rays (spec_cone).
 template <bool FULL, bool WIDE, bool CONE, bool TILED = false>
 __device__ __forceinline__ void run_env(const d2d_cfg &c, const d2d_state &s, int e, int lane, uint32_t stages,
-                                        const Geom &g, const LdsView &L, double action, EnvRegs &r, size_t noise_off = 0) {
+                                        const Geom &g, const LdsView &L, double action, EnvRegs &r, size_t noise_off = 0,
+                                        bool load_r = false) {
   using RayMask = std::conditional_t<WIDE, unsigned long long, unsigned int>;
   const int N = c.N, W = c.W, H = c.H;
   const double inv_scale = 1.0 / c.scale;
@@ -1510,22 +1525,55 @@ __device__ __forceinline__ void run_env(const d2d_cfg &c, const d2d_state &s, in
   // the five collision probes alone read global memory directly (staging the grid for them too -- one round trip fewer in the act
   // phase -- measured: no gain, 2.5 KB more traffic per env-step)
   const bool gt_staged = FULL && (do_ray || do_dyn);
+  const uint32_t needs_agents = D2D_ST_AGENTS | D2D_ST_RAYCAST | D2D_ST_DYNGRID | D2D_ST_TRACKER | D2D_ST_COLLIDE;
+  // a launch / phase whose agents are only read (collision test, trackers): their loads go out with the planner's result, ahead of
+  // the grid copies -- in the act phase of the persistent loop that is one round trip where there were three
+  const bool agents_light = (stages & needs_agents) && !(stages & (D2D_ST_AGENTS | D2D_ST_RAYCAST | D2D_ST_DYNGRID));
+  StepInRaw in_raw;
+  load_inputs_raw(c, s, e, do_ctl, in_raw);
+  // (the first 64 agents: loaded here, written to LDS where the agents stage stands below -- nothing waits in between)
+  double al_px = 0.0, al_py = 0.0, al_rr = 0.0;
+  unsigned char al_act = 0;
+  int al_kl = 1;
+  if (agents_light && lane < N) {
+    const double *__restrict__ ag = s.agents + (size_t)e * D2D_AF * N;
+    al_px = ag[D2D_A_PX * N + lane];
+    al_py = ag[D2D_A_PY * N + lane];
+    al_rr = ag[D2D_A_R * N + lane];
+    al_act = s.active[(size_t)e * N + lane];
+    if ((do_trk || do_col) && c.kf_enabled) al_kl = s.kf_len[(size_t)e * N + lane];
+  }
   if constexpr (FULL) {
     if (gt_staged) grid_stage(gt, L.gtw, W * H, lane);
     if (do_obs) grid_stage(dm, L.dmt, W * H, lane);
   }
+  // everything above is REQUESTED before anything below looks at a loaded value: left alone, the scheduler pulls the control
+  // stage's arithmetic up between the groups of loads, and each group then waits for the one before it (a round trip apiece)
+  // `load_r`: the env's registers are loaded HERE, last of the batch -- they come back through lane reads that wait where the loads
+  // stand (uniform values), which would hold everything requested after them back by a round trip
+  if (load_r) load_regs(s, e, r);
+  if (agents_light) __builtin_amdgcn_sched_barrier(0);
   StepIn in;
-  load_inputs(c, s, e, action, do_ctl, in);
+  finish_inputs(in_raw, action, in);
   D2D_STAMP(1);
   if (stages & D2D_ST_FSM) st_fsm(c, s, e, r);
   const double x0 = r.x, y0 = r.y, yaw0 = r.yaw;
   if (do_ctl) st_control(c, in, r);
   D2D_STAMP(2);
-  const uint32_t needs_agents = D2D_ST_AGENTS | D2D_ST_RAYCAST | D2D_ST_DYNGRID | D2D_ST_TRACKER | D2D_ST_COLLIDE;
   if (do_trk && c.kf_enabled && g.kf_lds) kf_stage(c, s, e, lane, L);
   if (stages & needs_agents) {
-    st_agents(c, s, e, lane, g, L, inv_scale, (stages & D2D_ST_AGENTS) != 0, do_trk || do_col,
-              !(stages & (D2D_ST_AGENTS | D2D_ST_RAYCAST | D2D_ST_DYNGRID)));
+    if (!agents_light) {
+      st_agents(c, s, e, lane, g, L, inv_scale, (stages & D2D_ST_AGENTS) != 0, do_trk || do_col, false);
+    } else {
+      if (lane < N) {
+        L.ax[lane] = al_px;
+        L.ay[lane] = al_py;
+        L.ar[lane] = al_rr;
+        L.act[lane] = al_act;
+        L.klen[lane] = al_kl;
+      }
+      if (N > WAVE) st_agents(c, s, e, lane, g, L, inv_scale, false, do_trk || do_col, true, WAVE);
+    }
     if (do_trk && !do_ray)  // hit mask of an earlier launch: stage it where the raycast leaves it
       for (int k = lane; k < N; k += WAVE) L.hit[k] = s.hit[(size_t)e * N + k];
     wave_sync_lds();
@@ -1999,10 +2047,9 @@ __device__ __attribute__((noinline)) void ph_gaze_stages(const ClosedArgs *ap, i
   const Geom g = make_geom(c, wpb, spec_ncap(SPEC), spec_full(SPEC));
   const LdsView L = carve(base, g, c.L);
   EnvRegs r;
-  load_regs(a->s, e, r);
   // this step's row of the measurement noise (d2d_cfg.noise_rows; utils.py:605 draws fresh normals every step)
   const size_t noise_off = c.noise_rows > 1 ? (size_t)((c.noise_row0 + tstep) % c.noise_rows) * c.B * c.N * 2 : 0;
-  run_env<spec_full(SPEC), spec_wide(SPEC), spec_cone(SPEC), spec_tiled(SPEC)>(c, a->s, e, lane, STAGES, g, L, a->s.action[e], r, noise_off);
+  run_env<spec_full(SPEC), spec_wide(SPEC), spec_cone(SPEC), spec_tiled(SPEC)>(c, a->s, e, lane, STAGES, g, L, a->s.action[e], r, noise_off, true);
   if (lane == 0) store_regs(a->s, e, r);
   wave_sync_global();
 #ifdef D2D_CHAIN_PROF
@@ -2021,8 +2068,7 @@ __device__ __attribute__((noinline)) void ph_stages(const ClosedArgs *ap, int e_
   const Geom g = make_geom(c, wpb, spec_ncap(SPEC), spec_full(SPEC));
   const LdsView L = carve(base, g, c.L);
   EnvRegs r;
-  load_regs(a->s, e, r);
-  run_env<spec_full(SPEC), spec_wide(SPEC), spec_cone(SPEC), spec_tiled(SPEC)>(c, a->s, e, lane, STAGES, g, L, a->s.action[e], r);
+  run_env<spec_full(SPEC), spec_wide(SPEC), spec_cone(SPEC), spec_tiled(SPEC)>(c, a->s, e, lane, STAGES, g, L, a->s.action[e], r, 0, true);
   if (lane == 0) store_regs(a->s, e, r);
   wave_sync_global();
 }

@@ -887,7 +887,10 @@ __device__ __forceinline__ void plan_carve(const d2d_cfg &c, const d2d_plan &p, 
 }
 
 // Writes the head step_pos will consume (utils.py:733-739) and the planner's result; pops the head.
-__device__ __forceinline__ void plan_emit(const d2d_state &s, const d2d_plan &p, int e, int lane, int head, int stored, int ok) {
+// `w_head`: the head waypoint (x, y, vx, vy) where the caller holds it already (lane 0), else null: read here -- both halves before
+// the first store (the stores could alias the loads for all the compiler knows: four dependent round trips otherwise).
+__device__ __forceinline__ void plan_emit(const d2d_state &s, const d2d_plan &p, int e, int lane, int head, int stored, int ok,
+                                          const double4 *w_head = nullptr) {
   if (lane == 0) {
     const double *traj = p.traj + (size_t)e * p.traj_cap * 4;
     int *hdr = p.traj_hdr + (size_t)e * 2;
@@ -895,8 +898,16 @@ __device__ __forceinline__ void plan_emit(const d2d_state &s, const d2d_plan &p,
     double *wp = (double *)s.wp + (size_t)e * 6;
     plan_ok[e] = (unsigned char)ok;
     if (stored - head > 0) {
-      const double *w = traj + (size_t)head * 4;
-      wp[0] = w[0]; wp[1] = w[1]; wp[2] = w[2]; wp[3] = w[3]; wp[4] = 0.0; wp[5] = 0.0;
+      double2 wa, wb;
+      if (w_head) {
+        wa = make_double2(w_head->x, w_head->y);
+        wb = make_double2(w_head->z, w_head->w);
+      } else {
+        const double *w = traj + (size_t)head * 4;
+        wa = ld2(w);
+        wb = ld2(w + 2);
+      }
+      wp[0] = wa.x; wp[1] = wa.y; wp[2] = wb.x; wp[3] = wb.y; wp[4] = 0.0; wp[5] = 0.0;
       wp_valid[e] = 1;
       head += 1;
     } else {
@@ -919,6 +930,10 @@ __device__ __forceinline__ bool plan_env_quick(const d2d_cfg &c, const d2d_state
   plan_carve(c, p, base, T, S);
   const double inv_scale = 1.0 / c.scale;
   const unsigned char *__restrict__ dm = s.dmap + (size_t)e * grid_bytes(c);
+  // the trajectory's header goes out with the trackers' loads below (it addresses the waypoints: a round trip of its own otherwise)
+  // (as a per-lane load, made uniform only behind the trackers' loads: a uniform load is waited for where it stands)
+  int *hdr = p.traj_hdr + (size_t)e * 2;
+  const int hdr_l = hdr[lane & 1];
   // ---- trackers: archive bookkeeping (utils.py:184,238) and the active ones into LDS ----
   int nact = 0;
   for (int k0 = 0; k0 < N; k0 += WAVE) {
@@ -955,10 +970,10 @@ __device__ __forceinline__ bool plan_env_quick(const d2d_cfg &c, const d2d_state
   }
   T.n = nact;
   wave_sync_lds();
+  int head = __builtin_amdgcn_readlane(hdr_l, 0), stored = __builtin_amdgcn_readlane(hdr_l, 1);
   // ---- replan_check, traj_planner.py:220-233 ----
-  int *hdr = p.traj_hdr + (size_t)e * 2;
-  int head = hdr[0], stored = hdr[1];
   double *__restrict__ traj = p.traj + (size_t)e * p.traj_cap * 4;
+  double4 w_first = make_double4(0.0, 0.0, 0.0, 0.0);  // lane 0: the head waypoint, what plan_emit hands to step_pos
   {
     const int n = stored - head;
     bool bad = false;
@@ -966,7 +981,10 @@ __device__ __forceinline__ bool plan_env_quick(const d2d_cfg &c, const d2d_state
       const int i = i0 + lane;
       if (i < n) {
         const double *w = traj + (size_t)(head + i) * 4;
-        const double wx = w[0], wy = w[1];
+        const double2 wxy = ld2(w), wv = ld2(w + 2);  // (x, y), (vx, vy)
+        const double4 w4 = make_double4(wxy.x, wxy.y, wv.x, wv.y);
+        if (i0 == 0) w_first = w4;
+        const double wx = w4.x, wy = w4.y;
         const double ti = (double)i * c.dt;
         const int ci = cell_fast(wx, c.scale, inv_scale), cj = cell_fast(wy, c.scale, inv_scale);
         const bool in = ci >= 0 && ci < c.W && cj >= 0 && cj < c.H;
@@ -1009,7 +1027,7 @@ __device__ __forceinline__ bool plan_env_quick(const d2d_cfg &c, const d2d_state
     wave_sync_lds();
     return true;
   }
-  plan_emit(s, p, e, lane, head, stored, 1);  // traj_planner.py:128-129: a non-empty trajectory is kept
+  plan_emit(s, p, e, lane, head, stored, 1, &w_first);  // traj_planner.py:128-129: a non-empty trajectory is kept
   return false;
 }
 
