@@ -468,6 +468,23 @@ __device__ __forceinline__ void finish_inputs(const StepInRaw &raw, double actio
   for (int i = 0; i < 6; ++i) in.wp[i] = raw.w[i];  // (read only where has_wp holds)
 }
 
+// the same in one step, with a branch around the loads: a launch of k_stages (run_env without `load_r`)
+__device__ __forceinline__ void load_inputs(const d2d_cfg &c, const d2d_state &s, int e, double action, bool control,
+                                            StepIn &in) {
+  in.action = action;
+  in.ok = true;
+  in.has_wp = false;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) in.wp[i] = 0.0;
+  if (control && c.planner_mode != D2D_PLANNER_NOMOVE) {
+    in.ok = s.plan_ok[e] != 0;
+    in.has_wp = s.wp_valid[e] != 0;
+    const double *wp = s.wp + (size_t)e * 6;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) in.wp[i] = wp[i];
+  }
+}
+
 // envs/drone_v2.py:197-214 with utils.py:733-743, 755-762 (lane-uniform scalar work)
 __device__ __forceinline__ void st_control(const d2d_cfg &c, const StepIn &in, EnvRegs &r) {
   if (c.planner_mode == D2D_PLANNER_NOMOVE) {
@@ -507,14 +524,132 @@ __device__ __forceinline__ void st_control(const d2d_cfg &c, const StepIn &in, E
 // moved agents and the staged tracker data land in LDS for the later stages.  With `move` false the
 // agents are only staged (a launch without the AGENTS stage).
 // `light`: only the collision test / the trackers follow (no rays, no dynamic grid): positions, radii and tracker flags.
+struct AgentIn {  // what the agents stage reads of one agent
+  double px, py, velx, vely, rr, r2;
+  int u, p0, p1, p2, klen;
+  unsigned char act;
+};
+
+// Loads of agent `k` (clamped into [0, N): callers pass any lane), WITHOUT a branch around them -- a block that ends behind its
+// loads is left only when they have arrived, a round trip ahead of whatever the caller requests next.  An env without agents reads
+// element 0 of its own pose / counters / flags instead (never used).
+// ANY_LANE false: the plain form for a caller that only comes here with k < N (k_stages' loop over the agents).
+template <bool ANY_LANE = true>
+__device__ __forceinline__ void agent_load(const d2d_cfg &c, const d2d_state &s, int e, int k, bool want_trk, AgentIn &a,
+                                           bool light = false) {
+  const int N = c.N;
+  const bool has = !ANY_LANE || N > 0, klen_on = has && want_trk && c.kf_enabled;
+  const int kk = ANY_LANE ? min(k, max(N, 1) - 1) : k;
+  const double *__restrict__ ag = has ? s.agents + (size_t)e * D2D_AF * N : s.drone + (size_t)e * D2D_DF;
+  const int *some_int = s.counters + (size_t)e * D2D_CF;
+  const int *__restrict__ prev = has ? s.dyn_prev + (size_t)e * N * 3 : some_int;
+  const int *unitp = has ? s.agent_unit + (size_t)e * N : some_int;
+  const int *klp = (!ANY_LANE || klen_on) ? s.kf_len + (size_t)e * N : some_int;
+  const unsigned char *actp = has ? s.active + (size_t)e * N : s.flags + (size_t)e * 4;
+  a.px = ag[D2D_A_PX * N + kk];
+  a.py = ag[D2D_A_PY * N + kk];
+  a.rr = ag[D2D_A_R * N + kk];
+  a.act = actp[kk];
+  a.velx = a.vely = a.r2 = 0.0;
+  a.u = a.p0 = a.p1 = a.p2 = 0;
+  if (!light) {  // (a constant in the persistent loop's phases; a branch -- cheap -- in a k_stages launch of the light stages alone)
+    a.velx = ag[D2D_A_VX * N + kk];
+    a.vely = ag[D2D_A_VY * N + kk];
+    a.r2 = ag[D2D_A_R2 * N + kk];
+    a.u = unitp[kk];
+    a.p0 = prev[3 * kk];
+    a.p1 = prev[3 * kk + 1];
+    a.p2 = prev[3 * kk + 2];
+  }
+  if constexpr (ANY_LANE) {
+    const int kl = klp[kk];
+    a.klen = klen_on ? kl : 1;
+  } else {
+    a.klen = 1;
+    if (klen_on) a.klen = klp[kk];
+  }
+}
+
+// envs/drone_v2.py:176-179 + utils.py:472-493 for agent k (loaded by agent_load): moved (`move`), written back and staged in LDS
+// for the later stages.  `light`: only the collision test / the trackers follow (no rays, no dynamic grid): positions, radii and
+// tracker flags.
+__device__ __forceinline__ void agent_apply(const d2d_cfg &c, const d2d_state &s, int e, int k, const LdsView &L, double inv_scale,
+                                            bool move, bool light, const AgentIn &a) {
+  const int N = c.N;
+  double *__restrict__ ag = s.agents + (size_t)e * D2D_AF * N;
+  const double cs = 0x1.bb67ae8584cabp-1, sn = 0x1.fffffffffffffp-2;  // cos(pi/6), sin(pi/6)
+  double px = a.px, py = a.py;
+  const double velx = a.velx, vely = a.vely, rr = a.rr;
+  if (light) {
+    L.ax[k] = px;
+    L.ay[k] = py;
+    L.ar[k] = rr;
+    L.act[k] = a.act;
+    L.klen[k] = a.klen;
+    return;
+  }
+  if (move) {
+    const double nx = px + velx * c.dt, ny = py + vely * c.dt;
+    bool aliased = true;
+    double pvx = velx, pvy = vely;
+    // norm(v) <= 5 (utils.py:476), numpy's norm = sqrt(fma(vy, vy, vx * vx)) (OpenBLAS ddot).  sqrt is correctly
+    // rounded and monotonic, and sqrt(s) rounds to <= 5 exactly for s <= nextafter(25) = 0x1.9000000000001p+4
+    // (checked on the host), so the fp64 sqrt is not needed.
+    if (__builtin_fma(vely, vely, velx * velx) <= 0x1.9000000000001p+4) {
+      // numpy 2x2 @ 2x1 (OpenBLAS dgemv): fma(M[r][0], v0, M[r][1] * v1); see oracle/d2d_oracle.c
+      const double rx = __builtin_fma(cs, velx, (-sn) * vely);
+      const double ry = __builtin_fma(sn, velx, cs * vely);
+      pvx = rx;
+      pvy = ry;
+      aliased = false;
+    }
+    if (nx < c.scale + rr) pvx = fabs(pvx);
+    else if (nx > c.W_px - c.scale - rr) pvx = -fabs(pvx);
+    if (ny < c.scale + rr) pvy = fabs(pvy);
+    else if (ny > c.H_px - c.scale - rr) pvy = -fabs(pvy);
+    const double ux = aliased ? pvx : velx, uy = aliased ? pvy : vely;
+    px = px + ux * c.dt;
+    py = py + uy * c.dt;
+    ag[D2D_A_PX * N + k] = px;
+    ag[D2D_A_PY * N + k] = py;
+    ag[D2D_A_VX * N + k] = pvx;
+    ag[D2D_A_VY * N + k] = pvy;
+  }
+  L.ax[k] = px;
+  L.ay[k] = py;
+  L.ar[k] = rr;
+  L.ar2[k] = a.r2;
+  L.ncx[k] = cell_fast(px, c.scale, inv_scale);
+  L.ncy[k] = cell_fast(py, c.scale, inv_scale);
+  L.nu[k] = a.u;
+  L.pcx[k] = a.p0;
+  L.pcy[k] = a.p1;
+  L.pu[k] = a.p2;
+  L.act[k] = a.act;
+  L.klen[k] = a.klen;
+}
+
+// lane = agent, from agent `k_first` on (the caller may have done the first 64 itself, loads and stores apart).  Batch-1 loads of
+// everything per-agent (agent planes, unit, previous dynamic block, tracker active / len) are issued together.  With `move` false
+// the agents are only staged (a launch without the AGENTS stage).
 __device__ __forceinline__ void st_agents(const d2d_cfg &c, const d2d_state &s, int e, int lane, const Geom &g,
                                           const LdsView &L, double inv_scale, bool move, bool want_trk, bool light = false,
                                           int k_first = 0) {
+  for (int k = k_first + lane; k < c.N; k += WAVE) {
+    AgentIn a;
+    agent_load(c, s, e, k, want_trk, a, light);
+    agent_apply(c, s, e, k, L, inv_scale, move, light, a);
+  }
+}
+
+// The agents stage as one loop, loads and stores together: a launch of k_stages (run_env without `load_r`).
+__device__ __forceinline__ void st_agents_plain(const d2d_cfg &c, const d2d_state &s, int e, int lane, const Geom &g,
+                                          const LdsView &L, double inv_scale, bool move, bool want_trk, bool light = false) {
   const int N = c.N;
   double *__restrict__ ag = s.agents + (size_t)e * D2D_AF * N;
   const int *__restrict__ prev = s.dyn_prev + (size_t)e * N * 3;
   const double cs = 0x1.bb67ae8584cabp-1, sn = 0x1.fffffffffffffp-2;  // cos(pi/6), sin(pi/6)
-  for (int k = k_first + lane; k < N; k += WAVE) {
+  for (int k = lane; k < N; k += WAVE) {
     double px = ag[D2D_A_PX * N + k], py = ag[D2D_A_PY * N + k];
     const double velx = ag[D2D_A_VX * N + k], vely = ag[D2D_A_VY * N + k];
     const double rr = ag[D2D_A_R * N + k];
@@ -1530,49 +1665,43 @@ __device__ __forceinline__ void run_env(const d2d_cfg &c, const d2d_state &s, in
   // the grid copies -- in the act phase of the persistent loop that is one round trip where there were three
   const bool agents_light = (stages & needs_agents) && !(stages & (D2D_ST_AGENTS | D2D_ST_RAYCAST | D2D_ST_DYNGRID));
   StepInRaw in_raw;
-  load_inputs_raw(c, s, e, do_ctl, in_raw);
-  // (the first 64 agents: loaded here, written to LDS where the agents stage stands below -- nothing waits in between)
-  double al_px = 0.0, al_py = 0.0, al_rr = 0.0;
-  unsigned char al_act = 0;
-  int al_kl = 1;
-  if (agents_light && lane < N) {
-    const double *__restrict__ ag = s.agents + (size_t)e * D2D_AF * N;
-    al_px = ag[D2D_A_PX * N + lane];
-    al_py = ag[D2D_A_PY * N + lane];
-    al_rr = ag[D2D_A_R * N + lane];
-    al_act = s.active[(size_t)e * N + lane];
-    if ((do_trk || do_col) && c.kf_enabled) al_kl = s.kf_len[(size_t)e * N + lane];
+  AgentIn ag0;
+  const bool agents_any = (stages & needs_agents) != 0;
+  // `load_r` (the phases of the persistent loop; the stage mask is a constant there): EVERYTHING the phase reads that does not hang
+  // on another load is requested before anything looks at a loaded value -- the planner's result, the first 64 agents (moved /
+  // written to LDS further down), the grid copies, the tracker block, and last the env's registers (they come back through lane
+  // reads that wait where the loads stand).  Left alone, the scheduler pulls the control stage's arithmetic up between the groups
+  // of loads and each group waits for the one before it: a round trip apiece, five in the act phase.
+  // A launch of k_stages keeps the plain order (its stage mask is a run-time value: the unconditional loads cost it 3 %).
+  if (load_r) {
+    load_inputs_raw(c, s, e, do_ctl, in_raw);
+    agent_load(c, s, e, lane, do_trk || do_col, ag0, agents_light);  // (every lane: no branch -- see agent_load)
   }
   if constexpr (FULL) {
     if (gt_staged) grid_stage(gt, L.gtw, W * H, lane);
     if (do_obs) grid_stage(dm, L.dmt, W * H, lane);
   }
-  // everything above is REQUESTED before anything below looks at a loaded value: left alone, the scheduler pulls the control
-  // stage's arithmetic up between the groups of loads, and each group then waits for the one before it (a round trip apiece)
-  // `load_r`: the env's registers are loaded HERE, last of the batch -- they come back through lane reads that wait where the loads
-  // stand (uniform values), which would hold everything requested after them back by a round trip
-  if (load_r) load_regs(s, e, r);
-  if (agents_light) __builtin_amdgcn_sched_barrier(0);
+  if (load_r) {
+    if (do_trk && c.kf_enabled && g.kf_lds) kf_stage(c, s, e, lane, L);
+    load_regs(s, e, r);
+    __builtin_amdgcn_sched_barrier(0);
+  }
   StepIn in;
-  finish_inputs(in_raw, action, in);
+  if (load_r) finish_inputs(in_raw, action, in);
+  else load_inputs(c, s, e, action, do_ctl, in);
   D2D_STAMP(1);
   if (stages & D2D_ST_FSM) st_fsm(c, s, e, r);
   const double x0 = r.x, y0 = r.y, yaw0 = r.yaw;
   if (do_ctl) st_control(c, in, r);
   D2D_STAMP(2);
-  if (do_trk && c.kf_enabled && g.kf_lds) kf_stage(c, s, e, lane, L);
-  if (stages & needs_agents) {
-    if (!agents_light) {
-      st_agents(c, s, e, lane, g, L, inv_scale, (stages & D2D_ST_AGENTS) != 0, do_trk || do_col, false);
+  if (!load_r && do_trk && c.kf_enabled && g.kf_lds) kf_stage(c, s, e, lane, L);
+  if (agents_any) {
+    const bool move = (stages & D2D_ST_AGENTS) != 0;
+    if (load_r) {
+      if (lane < N) agent_apply(c, s, e, lane, L, inv_scale, move, agents_light, ag0);
+      if (N > WAVE) st_agents(c, s, e, lane, g, L, inv_scale, move, do_trk || do_col, agents_light, WAVE);
     } else {
-      if (lane < N) {
-        L.ax[lane] = al_px;
-        L.ay[lane] = al_py;
-        L.ar[lane] = al_rr;
-        L.act[lane] = al_act;
-        L.klen[lane] = al_kl;
-      }
-      if (N > WAVE) st_agents(c, s, e, lane, g, L, inv_scale, false, do_trk || do_col, true, WAVE);
+      st_agents_plain(c, s, e, lane, g, L, inv_scale, move, do_trk || do_col, agents_light);
     }
     if (do_trk && !do_ray)  // hit mask of an earlier launch: stage it where the raycast leaves it
       for (int k = lane; k < N; k += WAVE) L.hit[k] = s.hit[(size_t)e * N + k];
