@@ -268,6 +268,7 @@ struct EnvRegs {  // lane-uniform per-env scalars carried in registers across th
   double x, y, yaw, vx, vy, ax, ay;
   double tx, ty;
   int steps, fail, sm, tnext, ntgt, tracked, bufn, bufts;
+  int done = -1;  // flags[D2D_F_DONE] as the collision stage of THIS call wrote it; -1: that stage did not run
 };
 
 // Python / numpy `int(v // s)` for integer-valued s > 0: the exact mathematical floor.  floor(v * (1/s))
@@ -1600,6 +1601,7 @@ __device__ __forceinline__ void st_collide(const d2d_cfg &c, const d2d_state &s,
     f[D2D_F_FREEZING] = (unsigned char)frz;
     f[D2D_F_DONE] = (unsigned char)done;
   }
+  r.done = done;
 }
 
 // utils.py:780-784 + envs/drone_v2.py:251-255: the crop is the LDS tile (loaded before the rays ran, zero
@@ -2155,18 +2157,20 @@ __device__ __attribute__((noinline)) void ph_plan_search(const ClosedArgs *ap, i
 }
 
 // gaze + the stages that follow it in one call (one set of callee-saved registers, one fence fewer per step)
+// `done_`: the env's episode flag as the caller knows it (the act phase of the step before returns it) -- no load, no round trip,
+// before the gaze stage can ask for anything else.  Returns the flag as this call's collision stage wrote it (-1: it did not run).
 template <int SPEC, uint32_t STAGES>
-__device__ __attribute__((noinline)) void ph_gaze_stages(const ClosedArgs *ap, int e_, int lds_off_, int t_) {
+__device__ __attribute__((noinline)) int ph_gaze_stages(const ClosedArgs *ap, int e_, int lds_off_, int t_, int done_) {
   const ArgsPtr a = uniform_ptr(ap);
   const int e = __builtin_amdgcn_readfirstlane(e_), lane = threadIdx.x & (WAVE - 1);
-  const int tstep = __builtin_amdgcn_readfirstlane(t_);
+  const int tstep = __builtin_amdgcn_readfirstlane(t_), known_done = __builtin_amdgcn_readfirstlane(done_);
   char *base = d2d_lds + __builtin_amdgcn_readfirstlane(lds_off_);
   d2d_cfg c = a->c;
   if (!spec_generic(SPEC)) spec_default_apply(c);
 #ifdef D2D_CHAIN_PROF
   const unsigned long long pp0 = __builtin_amdgcn_s_memtime();
 #endif
-  gaze_env(c, a->s, a->p, a->init, a->on_done == D2D_DONE_RESET, e, lane, base);
+  gaze_env(c, a->s, a->p, a->init, a->on_done == D2D_DONE_RESET, e, lane, base, known_done);
   wave_sync_global();
 #ifdef D2D_CHAIN_PROF
   D2D_PHASE_ADD(0, pp0);
@@ -2184,10 +2188,11 @@ __device__ __attribute__((noinline)) void ph_gaze_stages(const ClosedArgs *ap, i
 #ifdef D2D_CHAIN_PROF
   D2D_PHASE_ADD(1, pp1);
 #endif
+  return r.done;
 }
 
 template <int SPEC, uint32_t STAGES>
-__device__ __attribute__((noinline)) void ph_stages(const ClosedArgs *ap, int e_, int lds_off_) {
+__device__ __attribute__((noinline)) int ph_stages(const ClosedArgs *ap, int e_, int lds_off_) {
   const ArgsPtr a = uniform_ptr(ap);
   const int e = __builtin_amdgcn_readfirstlane(e_), lane = threadIdx.x & (WAVE - 1);
   char *base = d2d_lds + __builtin_amdgcn_readfirstlane(lds_off_);
@@ -2200,6 +2205,7 @@ __device__ __attribute__((noinline)) void ph_stages(const ClosedArgs *ap, int e_
   run_env<spec_full(SPEC), spec_wide(SPEC), spec_cone(SPEC), spec_tiled(SPEC)>(c, a->s, e, lane, STAGES, g, L, a->s.action[e], r, 0, true);
   if (lane == 0) store_regs(a->s, e, r);
   wave_sync_global();
+  return r.done;
 }
 
 template <int SPEC>
@@ -2221,16 +2227,18 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK, D2D_MIN_WAVES) void k_closed
   const unsigned long long cp0 = __builtin_amdgcn_s_memtime();
   unsigned long long cps = 0;
 #endif
+  // the env's episode flag, carried in a register from the collision stage that writes it to the gaze stage that asks for it
+  int flag_done = a->s.flags[(size_t)e * 4 + D2D_F_DONE] != 0 ? 1 : 0;
 #pragma unroll 1
   for (int t = 0; t < nsteps; ++t) {
-    if (freeze && a->s.flags[(size_t)e * 4 + D2D_F_DONE] != 0) break;  // one episode per env: it stays as it ended
+    if (freeze && flag_done != 0) break;  // one episode per env: it stays as it ended
     if (split) {
       // An env that searches often is the one the launch ends up waiting for (the worlds repeat, so it stays that env):
       // past one search per 32 steps of this launch all its phases issue first on their SIMD.  Its chain is
       // latency-bound, so the three waves it shares the SIMD with give up little.  (+4 % at 4096 envs; thresholds 16-64
       // and levels 1-2 measure the same, level 3 -- the search's own -- less.)
       if (nsearch * 32 > t + 16) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);
-      ph_gaze_stages<SPEC, D2D_ST_PERCEIVE>(a, e, off, t);
+      ph_gaze_stages<SPEC, D2D_ST_PERCEIVE>(a, e, off, t, flag_done);
 #ifdef D2D_CHAIN_PROF
       const unsigned long long q0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -2252,12 +2260,12 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK, D2D_MIN_WAVES) void k_closed
 #ifdef D2D_CHAIN_PROF
       const unsigned long long a0 = __builtin_amdgcn_s_memtime();
 #endif
-      ph_stages<SPEC, D2D_ST_ACT>(a, e, off);
+      flag_done = __builtin_amdgcn_readfirstlane(ph_stages<SPEC, D2D_ST_ACT>(a, e, off));
 #ifdef D2D_CHAIN_PROF
       D2D_PHASE_ADD(4, a0);
 #endif
     } else {
-      ph_gaze_stages<SPEC, D2D_ST_ALL>(a, e, off, t);
+      flag_done = __builtin_amdgcn_readfirstlane(ph_gaze_stages<SPEC, D2D_ST_ALL>(a, e, off, t, flag_done));
     }
   }
 #ifdef D2D_CHAIN_PROF

@@ -1191,8 +1191,9 @@ __host__ __device__ inline GazeGeom gaze_geom(const d2d_cfg &c, const d2d_plan &
 // The stage is a chain of small dependent loads (table rows of sin / cos, the seen map, the pairwise plan) rather
 // than arithmetic, so loads are batched: one sin / cos pass for all seven view directions, every lane's seen-map
 // cells fetched before the first is used, the pairwise plan staged in LDS.
+// `known_done`: the env's episode flag where the caller holds it (the persistent loop), -1: read here.
 __device__ __forceinline__ void gaze_env(const d2d_cfg &c, const d2d_state &s, const d2d_plan &p, const d2d_state &init,
-                                         int auto_reset, int e, int lane, char *base) {
+                                         int auto_reset, int e, int lane, char *base, int known_done = -1) {
   // ---- one batch of loads: everything the stage needs that does not hang on another load (the episode flag, the pose, the step
   //      count, the trajectory header, the table heads, the pairwise plan, the candidates' yaw rates) is requested before the first
   //      of them is looked at -- one round trip where the straightforward order makes seven dependent ones ----
@@ -1200,7 +1201,7 @@ __device__ __forceinline__ void gaze_env(const d2d_cfg &c, const d2d_state &s, c
   const GazeGeom g = gaze_geom(c, p);
   const double *dr = s.drone + (size_t)e * D2D_DF;
   const int *hdr = p.traj_hdr + (size_t)e * 2;
-  const unsigned char was_done = auto_reset ? s.flags[(size_t)e * 4 + D2D_F_DONE] : (unsigned char)0;
+  const int was_done = !auto_reset ? 0 : (known_done >= 0 ? known_done : (int)s.flags[(size_t)e * 4 + D2D_F_DONE]);
   double x0 = dr[D2D_D_X], y0 = dr[D2D_D_Y], yaw = dr[D2D_D_YAW];
   int steps = s.counters[(size_t)e * D2D_CF + D2D_C_STEPS];
   int head = 0, stored = 0;
