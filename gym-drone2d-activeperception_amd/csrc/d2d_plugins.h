@@ -1721,6 +1721,48 @@ __device__ __forceinline__ void gaze_env(const d2d_cfg &c, const d2d_state &s, c
     if (lane == 0) act[e] = ys_best / p.yaw_rate_max;  // :127
     return;
   }
+  // A tree of height h with 2^h blocks (at most 32) is the perfect one, its blocks in cell order: the 50 x 50 map's (32 blocks of 78 /
+  // 79 cells), every map whose recursion halves evenly.  Its additions are those of a butterfly over neighbouring lanes: lane = block
+  // (+ 32 for the odd candidates), four DPP row shifts and one lane read per candidate pair -- no LDS round trip per level, no table of
+  // additions.  Lanes past the last block hold +0.0 (x + 0.0 == x for the x >= +0.0 there are).
+  const int nlev_tree = p.pw_ntree - 3 * p.pw_nleaf;  // pw_tree = [n_levels, root, level_start[n_levels + 1], 3 ints per addition]
+  if (nlev_tree >= 0 && nlev_tree <= 5 && p.pw_nleaf == (1 << nlev_tree)) {
+    const int leaf = lane & 31, half = lane >> 5;
+    double v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int a = 2 * j + half;
+      const bool on = (a < p.n_yaw) & (leaf < p.pw_nleaf);
+      const double x = lsum[min(a, p.n_yaw - 1) * nnode + min(leaf, p.pw_nleaf - 1)];
+      v[j] = on ? x : 0.0;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {  // left + right at every level: the lower lane is the left operand
+      double x = v[j];
+      x = x + row_shl_f64<1>(x);
+      x = x + row_shl_f64<2>(x);
+      x = x + row_shl_f64<4>(x);
+      x = x + row_shl_f64<8>(x);
+      v[j] = x;
+    }
+    int best = 0;
+    double max_reward = 0.0;
+#pragma unroll
+    for (int a = 0; a < 7; ++a) {
+      if (a < p.n_yaw) {
+        const int l0 = 32 * (a & 1);
+        const double r = readlane_f64(v[a >> 1], l0) + readlane_f64(v[a >> 1], l0 + 16);  // blocks 0..15 + blocks 16..31
+        if (max_reward < r) {  // :116-125
+          best = a;
+          max_reward = r;
+        }
+      }
+    }
+    const double ys_best = shfl_f64(ys_l, best);
+    if (lane == 0) act[e] = ys_best / p.yaw_rate_max;  // :127
+    GZ(7);  // tree + argmax
+    return;
+  }
   {
     const int nlev = pwp[0];
     const int *ops = pwp + 3 + nlev;
