@@ -84,10 +84,17 @@ CASES = [
     # a 1000 x 800 px map (100 x 80 cells), deeper and wider view: the generic instantiation of every phase
     dict(B=4, T=60, chunk=12, agent_number=25, agent_radius=12, agent_max_speed=40, map_id=6, map_size=[1000, 800],
          drone_view_depth=120, drone_view_range=120, init_pos=[300, 400], target_list=[[900, 700]]),
+    # 52 x 40 = 2080 cells: numpy's pairwise recursion is NOT a perfect tree there (one half of a split is a block, the other splits
+    # again) -- the level-by-level additions of the gaze stage, not its butterfly
+    dict(B=6, T=80, chunk=8, agent_number=8, agent_radius=10, agent_max_speed=20, map_id=21, map_size=[520, 400],
+         init_pos=[60, 60], target_list=[[460, 340], [60, 340]]),
+    # 40 x 30 = 1200 cells: a perfect tree of 16 blocks (half the butterfly's lanes hold +0.0)
+    dict(B=6, T=80, chunk=8, agent_number=6, agent_radius=10, agent_max_speed=20, map_id=22, map_size=[400, 300],
+         init_pos=[50, 50], target_list=[[340, 240], [60, 240]]),
 ]
 
 
-@pytest.mark.parametrize('case', CASES, ids=lambda c: f"N{c['agent_number']}_B{c['B']}_v{c.get('drone_max_speed', 40)}")
+@pytest.mark.parametrize('case', CASES, ids=lambda c: f"N{c['agent_number']}_B{c['B']}_v{c.get('drone_max_speed', 40)}" + ('_%dx%d' % tuple(c['map_size']) if 'map_size' in c else ''))
 def test_closed_loop_matches_oracle(pkg, hip, oracle, case):
     """gaze -> perceive -> plan -> act with auto reset, `chunk` steps per call, compared after every call."""
     case = dict(case)
