@@ -1647,7 +1647,7 @@ __device__ __forceinline__ void store_regs(const d2d_state &s, int e, const EnvR
 template <bool FULL, bool WIDE, bool CONE, bool TILED = false>
 __device__ __forceinline__ void run_env(const d2d_cfg &c, const d2d_state &s, int e, int lane, uint32_t stages,
                                         const Geom &g, const LdsView &L, double action, EnvRegs &r, size_t noise_off = 0,
-                                        bool load_r = false) {
+                                        bool load_r = false, const StepIn *given = nullptr) {
   using RayMask = std::conditional_t<WIDE, unsigned long long, unsigned int>;
   const int N = c.N, W = c.W, H = c.H;
   const double inv_scale = 1.0 / c.scale;
@@ -1677,7 +1677,7 @@ __device__ __forceinline__ void run_env(const d2d_cfg &c, const d2d_state &s, in
   // A launch of k_stages keeps the plain order (its stage mask is a run-time value: the unconditional loads cost it 3 %).
   if (load_r) {
     in_raw.use = false;
-    if (do_ctl) load_inputs_raw(c, s, e, true, in_raw);  // (the stage mask is a constant here: no branch at run time)
+    if (do_ctl && !given) load_inputs_raw(c, s, e, true, in_raw);  // (the stage mask is a constant here: no branch at run time)
     agent_load(c, s, e, lane, do_trk || do_col, ag0, agents_light);  // (every lane: no branch -- see agent_load)
   }
   if constexpr (FULL) {
@@ -1690,8 +1690,14 @@ __device__ __forceinline__ void run_env(const d2d_cfg &c, const d2d_state &s, in
     __builtin_amdgcn_sched_barrier(0);
   }
   StepIn in;
-  if (load_r) finish_inputs(in_raw, action, in);
-  else load_inputs(c, s, e, action, do_ctl, in);
+  if (given) {  // the planner's result, handed over in registers (ph_plan_act)
+    in = *given;
+    in.action = action;
+  } else if (load_r) {
+    finish_inputs(in_raw, action, in);
+  } else {
+    load_inputs(c, s, e, action, do_ctl, in);
+  }
   D2D_STAMP(1);
   if (stages & D2D_ST_FSM) st_fsm(c, s, e, r);
   const double x0 = r.x, y0 = r.y, yaw0 = r.yaw;
@@ -2157,6 +2163,45 @@ __device__ __attribute__((noinline)) void ph_plan_search(const ClosedArgs *ap, i
   wave_sync_global();
 }
 
+// The planner's every-step part AND the act phase in one call, for the steps whose trajectory is kept (96 % of them): the
+// planner's result reaches the control stage in registers -- no store -> fence -> load between the two, one call, one scalar-load
+// round trip for the arguments, one fence fewer per step.  Returns -1 when Primitive.plan has to search (the caller runs
+// ph_plan_search and then ph_stages<ACT>), else the episode flag the collision stage wrote.
+template <int SPEC>
+__device__ __attribute__((noinline)) int ph_plan_act(const ClosedArgs *ap, int e_, int lds_off_) {
+  const ArgsPtr a = uniform_ptr(ap);
+  const int e = __builtin_amdgcn_readfirstlane(e_), lane = threadIdx.x & (WAVE - 1);
+  char *base = d2d_lds + __builtin_amdgcn_readfirstlane(lds_off_);
+  d2d_cfg c = a->c;
+  if (!spec_generic(SPEC)) spec_default_apply(c);
+  if constexpr (SPEC == 1 || SPEC == 2) {  // folds the size of the search's cost mirror (search_lds_nodes)
+    constexpr int cap = spec_ncap(SPEC);
+    __builtin_assume(c.N <= cap);
+  }
+  double4 w_head;
+  const bool need = plan_env_quick(c, a->s, a->p, e, lane, base, &w_head);
+  if (need) {
+    wave_sync_global();
+    return -1;
+  }
+  // (nothing the act phase loads was written above: the planner's stores are its own state and the result handed over here;
+  // its LDS staging has drained before the act phase's copies land in the same bytes)
+  wave_sync_lds();
+  StepIn in;
+  in.action = 0.0;
+  in.ok = true;
+  in.has_wp = true;
+  in.wp[0] = w_head.x; in.wp[1] = w_head.y; in.wp[2] = w_head.z; in.wp[3] = w_head.w; in.wp[4] = 0.0; in.wp[5] = 0.0;
+  const int wpb = (SPEC == 1 || SPEC == 2) ? WAVES_PER_BLOCK : (int)(blockDim.x / WAVE);
+  const Geom g = make_geom(c, wpb, spec_ncap(SPEC), spec_full(SPEC));
+  const LdsView L = carve(base, g, c.L);
+  EnvRegs r;
+  run_env<spec_full(SPEC), spec_wide(SPEC), spec_cone(SPEC), spec_tiled(SPEC)>(c, a->s, e, lane, D2D_ST_ACT, g, L, a->s.action[e], r, 0, true, &in);
+  if (lane == 0) store_regs(a->s, e, r);
+  wave_sync_global();
+  return r.done;
+}
+
 // gaze + the stages that follow it in one call (one set of callee-saved registers, one fence fewer per step)
 // `done_`: the env's episode flag as the caller knows it (the act phase of the step before returns it) -- no load, no round trip,
 // before the gaze stage can ask for anything else.  Returns the flag as this call's collision stage wrote it (-1: it did not run).
@@ -2246,11 +2291,12 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK, D2D_MIN_WAVES) void k_closed
 #ifdef D2D_CHAIN_PROF
       const unsigned long long q0 = __builtin_amdgcn_s_memtime();
 #endif
-      const int need = __builtin_amdgcn_readfirstlane(ph_plan_quick<SPEC>(a, e, off));
+      // the planner's every-step part and, unless it has to search, the act phase behind it in the same call (ph_plan_act)
+      const int pa = __builtin_amdgcn_readfirstlane(ph_plan_act<SPEC>(a, e, off));
 #ifdef D2D_CHAIN_PROF
-      D2D_PHASE_ADD(2, q0);
+      D2D_PHASE_ADD(2, q0);  // (planner every-step part + act of the steps without a search)
 #endif
-      if (need) {
+      if (pa < 0) {
 #ifdef D2D_CHAIN_PROF
         const unsigned long long s0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -2259,15 +2305,15 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK, D2D_MIN_WAVES) void k_closed
 #ifdef D2D_CHAIN_PROF
         cps += __builtin_amdgcn_s_memtime() - s0;
         D2D_PHASE_ADD(3, s0);
+        const unsigned long long a0 = __builtin_amdgcn_s_memtime();
 #endif
+        flag_done = __builtin_amdgcn_readfirstlane(ph_stages<SPEC, D2D_ST_ACT>(a, e, off));
+#ifdef D2D_CHAIN_PROF
+        D2D_PHASE_ADD(4, a0);  // (act of the steps with a search)
+#endif
+      } else {
+        flag_done = pa;
       }
-#ifdef D2D_CHAIN_PROF
-      const unsigned long long a0 = __builtin_amdgcn_s_memtime();
-#endif
-      flag_done = __builtin_amdgcn_readfirstlane(ph_stages<SPEC, D2D_ST_ACT>(a, e, off));
-#ifdef D2D_CHAIN_PROF
-      D2D_PHASE_ADD(4, a0);
-#endif
     } else {
       flag_done = __builtin_amdgcn_readfirstlane(ph_gaze_stages<SPEC, D2D_ST_ALL>(a, e, off, t, flag_done));
     }

@@ -923,7 +923,10 @@ __device__ __forceinline__ void plan_emit(const d2d_state &s, const d2d_plan &p,
 // that follows finds them), replan_check, and -- when the trajectory is still there -- its head.  Returns true when
 // the trajectory is empty, i.e. Primitive.plan has to search (plan_env_search).  Kept apart from the search so that,
 // as a called function in the persistent loop, the common path does not pay the search's register saves.
-__device__ __forceinline__ bool plan_env_quick(const d2d_cfg &c, const d2d_state &s, const d2d_plan &p, int e, int lane, char *base) {
+// `w_head_out` (optional): where the trajectory is kept, the head waypoint plan_emit stored (x, y, vx, vy), wave-uniform -- the
+// act phase of the persistent loop takes it from there instead of reading the planner's result back from memory.
+__device__ __forceinline__ bool plan_env_quick(const d2d_cfg &c, const d2d_state &s, const d2d_plan &p, int e, int lane, char *base,
+                                               double4 *w_head_out = nullptr) {
   const int N = c.N;
   TrkView T;
   SearchLds S;
@@ -1028,6 +1031,8 @@ __device__ __forceinline__ bool plan_env_quick(const d2d_cfg &c, const d2d_state
     return true;
   }
   plan_emit(s, p, e, lane, head, stored, 1, &w_first);  // traj_planner.py:128-129: a non-empty trajectory is kept
+  if (w_head_out)
+    *w_head_out = make_double4(readlane_f64(w_first.x, 0), readlane_f64(w_first.y, 0), readlane_f64(w_first.z, 0), readlane_f64(w_first.w, 0));
   return false;
 }
 

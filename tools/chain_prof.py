@@ -43,7 +43,7 @@ for rep in range(2):
     for e in top:
         print(f'  env {e:5d}: chain {chain[e] / clk / 1e3:7.2f} ms, searches {ns[e]:4d}, search time {srch[e] / clk / 1e3:7.2f} ms, per step w/o search {(chain[e] - srch[e]) / clk / STEPS:6.1f} us')
     ph = phase.cpu().numpy().astype(np.float64) / clk / STEPS          # us per step and phase
-    names = ['gaze', 'perceive', 'planner every-step part', 'search', 'act']
+    names = ['gaze', 'perceive', 'planner every-step part + act (one call unless a search follows)', 'search', 'act behind a search']
     print('per-step time by phase (us), mean over envs / the 16 longest chains: ' + ', '.join(
         f'{n} {ph[:, i].mean():.1f} / {ph[np.argsort(chain)[-16:], i].mean():.1f}' for i, n in enumerate(names)))
     gz = ['tables + directions', 'seen pass', 'swept map + fence', 'live cells', 'rewards + bits', 'hot blocks', 'block sums', 'tree + argmax']
