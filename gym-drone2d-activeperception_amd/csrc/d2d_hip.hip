@@ -1663,18 +1663,19 @@ __device__ __forceinline__ void run_env(const d2d_cfg &c, const d2d_state &s, in
   // phase -- measured: no gain, 2.5 KB more traffic per env-step)
   const bool gt_staged = FULL && (do_ray || do_dyn);
   const uint32_t needs_agents = D2D_ST_AGENTS | D2D_ST_RAYCAST | D2D_ST_DYNGRID | D2D_ST_TRACKER | D2D_ST_COLLIDE;
-  // a launch / phase whose agents are only read (collision test, trackers): their loads go out with the planner's result, ahead of
-  // the grid copies -- in the act phase of the persistent loop that is one round trip where there were three
+  // a launch / phase whose agents are only read (collision test, trackers): positions, radii and tracker flags are all it stages
   const bool agents_light = (stages & needs_agents) && !(stages & (D2D_ST_AGENTS | D2D_ST_RAYCAST | D2D_ST_DYNGRID));
   StepInRaw in_raw;
   AgentIn ag0;
   const bool agents_any = (stages & needs_agents) != 0;
-  // `load_r` (the phases of the persistent loop; the stage mask is a constant there): EVERYTHING the phase reads that does not hang
-  // on another load is requested before anything looks at a loaded value -- the planner's result, the first 64 agents (moved /
-  // written to LDS further down), the grid copies, the tracker block, and last the env's registers (they come back through lane
-  // reads that wait where the loads stand).  Left alone, the scheduler pulls the control stage's arithmetic up between the groups
-  // of loads and each group waits for the one before it: a round trip apiece, five in the act phase.
-  // A launch of k_stages keeps the plain order (its stage mask is a run-time value: the unconditional loads cost it 3 %).
+  // `load_r` (the act phase of the persistent loop; the stage mask is a constant there): EVERYTHING the phase reads that does not
+  // hang on another load is requested before anything looks at a loaded value -- the planner's result (unless the caller hands it
+  // over in registers: `given`), the first 64 agents (written to LDS further down), the grid copies, the tracker block, and last
+  // the env's registers (they come back through lane reads that wait where the loads stand).  Left alone, the scheduler pulls the
+  // control stage's arithmetic up between the groups of loads and each group waits for the one before it: a round trip apiece,
+  // five in the act phase.  The perceive phase and a launch of k_stages keep the plain order: the first holds too many registers
+  // across the grid copies this way (13 instead of 6 callee-saved registers saved per call), the second has a run-time stage mask
+  // (unconditional loads and pointer selects cost it 3 %).
   if (load_r) {
     in_raw.use = false;
     if (do_ctl && !given) load_inputs_raw(c, s, e, true, in_raw);  // (the stage mask is a constant here: no branch at run time)
