@@ -63,6 +63,42 @@ def test_pairwise_plan_is_numpy_sum(pkg):
             assert np.sum(a) == DP.pairwise_sum_host(list(a.ravel()), leaves, prog)
 
 
+def test_perfect_addition_trees_are_butterflies(pkg):
+    """What the gaze stage's butterfly over lanes (csrc/d2d_plugins.h: a tree of height h with 2^h blocks, h <= 5) relies on, for
+    every map size of the dense path: pw_ntree - 3 pw_nleaf is the tree's height; such a tree adds neighbouring nodes in cell
+    order at every level (node 2k + node 2k + 1, left operand first), which is what `v + row_shl(v)` per level computes; and a
+    butterfly over zero-padded lanes gives numpy's sum bit for bit."""
+    from drone2d_amd import device_plugins as DP
+    rng = np.random.RandomState(11)
+    seen_perfect = seen_other = 0
+    for n in list(range(1, 4097, 7)) + [2500, 3600, 4096, 1200, 2080, 260]:
+        leaves, prog = DP.pairwise_plan(n)
+        ops, start, root = DP.pairwise_levels(len(leaves), prog)
+        nlev, nleaf = len(start) - 1, len(leaves)
+        ntree = 2 + len(start) + 3 * len(ops)                   # [n_levels, root, level_start[n_levels + 1], 3 ints per addition]
+        assert ntree - 3 * nleaf == nlev
+        if nleaf != (1 << nlev) or nlev > 5:
+            seen_other += 1
+            continue
+        seen_perfect += 1
+        prev = list(range(nleaf))                               # node ids of the level below, in cell order
+        for lv in range(nlev):
+            level = [tuple(int(x) for x in o) for o in ops[start[lv]:start[lv + 1]]]
+            assert len(level) == len(prev) // 2
+            assert [(a, b) for _, a, b in level] == [(prev[2 * k], prev[2 * k + 1]) for k in range(len(level))]
+            prev = [d for d, _, _ in level]
+        assert prev == [root]
+        # the butterfly itself on 32 zero-padded lanes against numpy
+        a = np.where(rng.rand(n) < 0.2, rng.choice([1e6, 1000.0, 0.3, 0.7, 1.0], size=n), 0.0)
+        lane = [0.0] * 32
+        for k, (off, m) in enumerate(leaves):
+            lane[k] = float(np.sum(a[off:off + m]))             # a block: numpy's own 8-accumulator sum
+        for sh in (1, 2, 4, 8, 16):
+            lane = [lane[i] + lane[i + sh] if i + sh < 32 else lane[i] for i in range(32)]
+        assert lane[0] == float(np.sum(a))
+    assert seen_perfect > 100 and seen_other > 50
+
+
 def test_acos_window_is_this_hosts_arccos(pkg):
     from drone2d_amd import device_plugins as DP
     rng = np.random.RandomState(4)
