@@ -1553,6 +1553,161 @@ __device__ __forceinline__ void st_tracker_elem(const d2d_cfg &c, const d2d_stat
   r.bufts += wave_sum(arch_ts);
 }
 
+// Value of lane Q (0..3) of the lane's quad: a DPP quad_perm broadcast, no LDS round trip.  Every lane of the quad must be
+// executing (the callers keep the whole wave in step and predicate their stores instead).
+template <int Q>
+__device__ __forceinline__ double quad_bcast_f64(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, Q * 0x55, 0xf, 0xf, false);  // quad_perm:[Q,Q,Q,Q]
+  hi = __builtin_amdgcn_update_dpp(hi, hi, Q * 0x55, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+
+// The same stage with FOUR LANES PER TRACKER, lane = one COLUMN j of the tracker's state (mu[j] and Sigma[0..3][j]), 16 trackers
+// per pass over the list of those that have anything to do (active, or hit this step): the form for more than 16 agents.
+// With a lane per tracker the stage holds a whole filter in registers -- 16 + 8 + 8 doubles, the register peak of every kernel
+// and phase that contains it (121 VGPRs against 82 without it; in the persistent loop the gaze + perceive phase saved and
+// restored 40 callee-saved registers per call for it: 11 KB of scratch writes per env-step) -- and issues the filter's ~170
+// instructions for the few lanes whose tracker is active.  The filter is column-local except for three hand-offs inside the quad
+// (DPP quad_perm broadcasts, no LDS): predict() adds column j + 2 to column j < 2 (the lane loads both), the archive test reads
+// Sigma[0][0], mu[0], mu[1], and update() needs columns 0 and 1 for the gain.  A lane then holds its own column (4 doubles), the
+// two broadcast columns (8) and one row of the gain at a time.  Every element is the expression the sequential code evaluates for
+// it, operand for operand (F and H are 0 / 1 / 0.1: the dense products collapse without changing a rounding): bit-identical state.
+template <bool KF_LDS>
+__device__ __forceinline__ void st_tracker_quad(const d2d_cfg &c, const d2d_state &s, int e, int lane, const Geom &g,
+                                                const LdsView &L, EnvRegs &r, size_t noise_off) {
+  const int N = c.N;
+  if (!c.kf_enabled) {
+    for (int k = lane; k < N; k += WAVE)
+      if (L.hit[k] != 0 && L.act[k] == 0) s.active[(size_t)e * N + k] = 1;
+    return;
+  }
+  // the trackers with anything to do, in index order -- into the ray candidates' planes, which nothing reads after the raycast
+  // (cx .. crr are contiguous: room for 16 * ccap >= N indices)
+  short *list = (short *)L.cx;
+  int nwork = 0;
+  for (int k0 = 0; k0 < N; k0 += WAVE) {
+    const int k = k0 + lane;
+    const bool need = k < N && (L.act[k] != 0 || L.hit[k] != 0);
+    const unsigned long long m = __ballot(need);
+    if (need) list[nwork + __popcll(m & ((1ull << lane) - 1ull))] = (short)k;
+    nwork += __popcll(m);
+  }
+  if (nwork == 0) return;
+  wave_sync_lds();
+  const int slot = lane >> 2, j = lane & 3, jp = j < 2 ? j + 2 : j;   // the column predict() adds to column j < 2
+  const double qn = (c.sigma != 0.0) ? 0.1 : 0.001;
+  int arch_n = 0, arch_ts = 0;
+  for (int q0 = 0; q0 < nwork; q0 += WAVE / 4) {
+    const bool on = q0 + slot < nwork;
+    const int k = (int)list[on ? q0 + slot : q0];
+    const bool has_z = L.hit[k] != 0, act = L.act[k] != 0;
+    double *__restrict__ gk = s.kf + ((size_t)e * N + k) * D2D_KF;
+    // ten loads per lane in flight: mu[j], mu[jp], columns j and jp (two instantiations: a run-time choice between an LDS and a
+    // global pointer would become flat loads)
+    auto old = [&](int el) -> double {
+      if constexpr (KF_LDS) return L.kf[k * D2D_KF + el];
+      else return gk[el];
+    };
+    const double mj = old(j), mp = old(jp);
+    double A[4], Bc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      A[i] = old(4 + 4 * i + j);
+      Bc[i] = old(4 + 4 * i + jp);
+    }
+    const int klen = L.klen[k];
+    double zx = L.ax[k], zy = L.ay[k];
+    if (s.noise) {
+      zx = zx + c.sigma * s.noise[noise_off + ((size_t)e * N + k) * 2];
+      zy = zy + c.sigma * s.noise[noise_off + ((size_t)e * N + k) * 2 + 1];
+    }
+    // ---- predict(), utils.py:225-240: mu <- F mu ; S <- F S ; S <- S F^T ; S += Q (computed by all, selected below) ----
+    double m = j < 2 ? mj + 0.1 * mp : mj;
+    A[0] = A[0] + 0.1 * A[2];     // F S on the own column ...
+    A[1] = A[1] + 0.1 * A[3];
+    Bc[0] = Bc[0] + 0.1 * Bc[2];  // ... and on the column S F^T adds to it
+    Bc[1] = Bc[1] + 0.1 * Bc[3];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const double t = A[i] + Bc[i] * 0.1;
+      A[i] = j < 2 ? t : A[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const double t = A[i] + qn;
+      A[i] = i == j ? t : A[i];
+    }
+    int len = klen + 1;
+    const double p00 = quad_bcast_f64<0>(A[0]), pm0 = quad_bcast_f64<0>(m), pm1 = quad_bcast_f64<1>(m);
+    const bool archive = act && (p00 >= 150.0 || !(c.kf_lo_x < pm0 && pm0 < c.kf_hi_x) || !(c.kf_lo_y < pm1 && pm1 < c.kf_hi_y));
+    if (archive && on && j == 0) {
+      arch_n += 1;  // archived copy -> tracker_buffer
+      arch_ts += len;
+    }
+    // the state update() (if any) starts from: the prediction, or a fresh filter's (KalmanFilter.__init__: mu 0, Sigma diag(1, 1, 10, 10))
+    // after an archive / before the first sighting
+    const bool fresh = archive || !act;
+    if (fresh) len = 1;
+    m = fresh ? 0.0 : m;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) A[i] = fresh ? (i == j ? (i < 2 ? 1.0 : 10.0) : 0.0) : A[i];
+    double om = m, O[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) O[i] = A[i];
+    {  // update(), utils.py:249-260 (also runs on the freshly reset filter); computed by all, selected below
+      double C0[4], C1[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        C0[i] = quad_bcast_f64<0>(A[i]);
+        C1[i] = quad_bcast_f64<1>(A[i]);
+      }
+      const double m0 = quad_bcast_f64<0>(m), m1 = quad_bcast_f64<1>(m);
+      const double a = c.sigma + C0[0], b = C1[0], cc = C0[1], d = c.sigma + C1[1];
+      const double det = a * d - b * cc;
+      const double idet = 1.0 / det;  // inv(S) through one reciprocal (same in oracle/d2d_oracle.c)
+      const double i00 = d * idet, i01 = -b * idet, i10 = -cc * idet, i11 = a * idet;
+      const double rx = zx - m0, ry = zy - m1;
+      const double s0 = A[0], s1 = A[1];
+      double Kj0 = 0.0, Kj1 = 0.0;  // the gain's row j, for mu[j]
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const double K0 = C0[i] * i00 + C1[i] * i10, K1 = C0[i] * i01 + C1[i] * i11;
+        Kj0 = i == j ? K0 : Kj0;
+        Kj1 = i == j ? K1 : Kj1;
+        // S <- (I - K H) S on the own column: rows 2, 3 add to themselves, rows 0, 1 are replaced
+        if (i >= 2) O[i] = ((0.0 - K0) * s0 + (0.0 - K1) * s1) + A[i];
+        else if (i == 0) O[i] = (1.0 - K0) * s0 + (0.0 - K1) * s1;
+        else O[i] = (0.0 - K0) * s0 + (1.0 - K1) * s1;
+      }
+      om = m + (Kj0 * rx + Kj1 * ry);
+    }
+    if (!act) {  // first sighting, utils.py:263-273 (has_z holds: the tracker is on the list)
+      om = j == 0 ? zx : (j == 1 ? zy : 0.0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) O[i] = A[i];
+    } else if (!has_z) {
+      om = m;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) O[i] = A[i];
+    }
+    if (on) {
+      gk[j] = om;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) gk[4 + 4 * i + j] = O[i];
+      if (j == 0) {
+        const unsigned char nact = (act && archive) ? 0 : 1;  // predict() re-initialised the filter (utils.py:238): inactive, even if update() then corrects it
+        s.kf_len[(size_t)e * N + k] = len;
+        s.active[(size_t)e * N + k] = nact;
+        L.act[k] = nact;
+        L.klen[k] = len;
+      }
+    }
+  }
+  r.bufn += wave_sum(arch_n);
+  r.bufts += wave_sum(arch_ts);
+}
+
 // utils.py:764-778 + envs/drone_v2.py:217-235.  `probe_wall`: the lane's batch-2 static probe (lane < 5).
 __device__ __forceinline__ void st_collide(const d2d_cfg &c, const d2d_state &s, int e, int lane, const LdsView &L,
                                            bool probe_wall, EnvRegs &r) {
@@ -1861,8 +2016,13 @@ __device__ __forceinline__ void run_env(const d2d_cfg &c, const d2d_state &s, in
     if (FULL && g.ncap <= 16) {
       st_tracker_elem(c, s, e, lane, g, L, r, noise_off);
     } else {
+#ifdef D2D_TRK_LANE
       if (g.kf_lds) st_tracker<true>(c, s, e, lane, g, L, r, noise_off);
       else st_tracker<false>(c, s, e, lane, g, L, r, noise_off);
+#else
+      if (g.kf_lds) st_tracker_quad<true>(c, s, e, lane, g, L, r, noise_off);
+      else st_tracker_quad<false>(c, s, e, lane, g, L, r, noise_off);
+#endif
     }
   }
 #endif
