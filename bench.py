@@ -310,7 +310,38 @@ def launch_ranks(n):
                    MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
         procs.append(subprocess.Popen([sys.executable, entry] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out0, _ = procs[0].communicate()
+    # rank 0's line is read by a thread while ALL children are polled: a rank that dies early (out of memory, a bad GPU, an
+    # import error) would otherwise leave the others in their first collective until its timeout, and this parent with them
+    import threading
+    buf = []
+    reader = threading.Thread(target=lambda: buf.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+
+    def stop_all(*_):
+        for q in procs:
+            if q.poll() is None:
+                q.terminate()
+        for q in procs:
+            try:
+                q.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                q.kill()
+
+    import signal
+    old_term = signal.signal(signal.SIGTERM, lambda *a: (stop_all(), sys.exit(1)))
+    try:
+        while any(q.poll() is None for q in procs):
+            if any(q.poll() not in (None, 0) for q in procs):
+                stop_all()
+                break
+            time.sleep(0.2)
+    except KeyboardInterrupt:
+        stop_all()
+        raise
+    finally:
+        signal.signal(signal.SIGTERM, old_term)
+    reader.join(timeout=10)
+    out0 = buf[0] if buf else ''
     codes = [p.wait() for p in procs]
     if any(codes):
         sys.stdout.write(out0)

@@ -30,6 +30,7 @@
 // reference's runtime performs: libm tan, OpenBLAS dgemv), which is what makes the integer outputs
 // bit-exact.  Stage -> reference map: see include/d2d.h D2D_ST_*.
 #include <hip/hip_runtime.h>
+#include <math.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -563,7 +564,7 @@ __device__ __forceinline__ void agent_load(const d2d_cfg &c, const d2d_state &s,
     a.p2 = prev[3 * kk + 2];
   }
   if constexpr (ANY_LANE) {
-    const int kl = klp[kk];
+    const int kl = klp[klen_on ? kk : 0];  // (the stand-in pointer holds D2D_CF ints, not N: only its element 0 may be touched)
     a.klen = klen_on ? kl : 1;
   } else {
     a.klen = 1;
@@ -2641,6 +2642,17 @@ int plan_check(const d2d_cfg *c, const d2d_state *s, const d2d_plan *p) {
     if (p->nu <= 0 || p->n_sample <= 0 || p->n_ts <= 0 || p->traj_cap < p->n_ts || p->node_cap < 2)
       return fail(-1, "plan: bad planner dimensions");
     if (!s->plan_ok || !s->wp_valid || !s->wp) return fail(-1, "plan: plan_ok / wp_valid / wp buffers missing");
+    // the squared thresholds a caller hands over must be THE thresholds of vmax / goal_tol: the search trusts them
+    if (p->vmax_sq != 0.0) {
+      const bool none = !(p->vmax > 0.0);  // nothing is `< vmax`: the caller says so with -1
+      const bool ok = none ? p->vmax_sq == -1.0
+                           : (p->vmax_sq > 0.0 && sqrt(p->vmax_sq) < p->vmax && sqrt(nextafter(p->vmax_sq, INFINITY)) >= p->vmax);
+      if (!ok) return fail(-1, "plan: vmax_sq is not the largest s with sqrt(s) < vmax (0 = let the library find it; -1 when vmax <= 0)");
+    }
+    if (p->goal_sq != 0.0) {
+      const bool ok = p->goal_tol >= 0.0 && p->goal_sq >= 0.0 && sqrt(p->goal_sq) <= p->goal_tol && sqrt(nextafter(p->goal_sq, INFINITY)) > p->goal_tol;
+      if (!ok) return fail(-1, "plan: goal_sq is not the largest s with sqrt(s) <= goal_tol (0 = let the library find it)");
+    }
     if ((size_t)plan_wave_bytes(c->N, p->nu, p->n_sample, c->W, c->H) > LDS_HARD) return fail(-4, "plan: too many agents for the tracker staging in LDS");
   }
   if (p->gaze == D2D_GAZE_OXFORD) {
@@ -2649,9 +2661,8 @@ int plan_check(const d2d_cfg *c, const d2d_state *s, const d2d_plan *p) {
     if (p->n_yaw <= 0 || p->n_yaw > 7) return fail(-4, "gaze: at most 7 yaw-rate candidates");
     if (p->pw_nleaf <= 0 || p->pw_nprog != 2 * p->pw_nleaf - 1 || p->pw_ntree < 3) return fail(-1, "gaze: bad pairwise-sum program");
     if ((size_t)gaze_geom(*c, *p).wave_bytes > LDS_HARD)
-      return fail(-4, "gaze: map / view depth too large for the per-env LDS working set");
-    if (gaze_geom(*c, *p).sparse && gaze_geom(*c, *p).bbn > 32)
-      return fail(-4, "gaze: view depth above 13 cells on a map of more than 4096 cells (two blocks of numpy's pairwise sum per box row, 64 in all)");
+      return fail(-4, "gaze: map / view depth too large for the per-env LDS working set (above 4096 cells a view deeper than 13 cells "
+                      "needs the whole pairwise-sum plan of the map in LDS)");
     if ((long long)c->W * c->H >= (1ll << 24)) return fail(-4, "gaze: maps of 2^24 cells and more are not supported");
     if (gaze_geom(*c, *p).bbn > 64 || c->W * c->H < 64)
       return fail(-4, "gaze: view depth above 29 cells or a map below 64 cells");

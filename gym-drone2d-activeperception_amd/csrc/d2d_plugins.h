@@ -1179,6 +1179,9 @@ __host__ __device__ inline GazeGeom gaze_geom(const d2d_cfg &c, const d2d_plan &
   g.bbn = 2 * ((int)(c.depth / c.scale) + 1) + 3;
   g.ncell = g.bbn * g.bbn;
   g.sparse = (c.W * c.H > D2D_GAZE_DENSE_CELLS) ? 1 : 0;
+  // the sparse path holds two blocks per box row, D2D_GAZE_HOT in all: a view box deeper than that (above 13 cells of view depth)
+  // takes the dense plan whatever the map's size -- while it fits the wave's LDS (plan_check)
+  if (g.sparse && 2 * g.bbn > D2D_GAZE_HOT) g.sparse = 0;
   g.nleaf = g.sparse ? D2D_GAZE_HOT : p.pw_nleaf;
   g.ntree = g.sparse ? 2 * D2D_GAZE_HOT : p.pw_ntree;  // sparse: depth and path of every hot block in numpy's recursion
   g.nnode = g.sparse ? D2D_GAZE_HOT : 2 * p.pw_nleaf - 1;

@@ -62,6 +62,9 @@ def gather_episode_stats(env, total_envs=None):
         return stats
     world = dist.get_world_size()
     total = total_envs if total_envs is not None else None
+    home = stats.device
+    if dist.get_backend() == 'gloo':   # (a dry run of the multi-rank path on one box: the collective runs on host tensors)
+        stats = stats.cpu()
     n_local = torch.tensor([stats.shape[0]], dtype=torch.int64, device=stats.device)
     sizes = [torch.zeros_like(n_local) for _ in range(world)]
     dist.all_gather(sizes, n_local)
@@ -71,7 +74,7 @@ def gather_episode_stats(env, total_envs=None):
     pad[:stats.shape[0]] = stats
     parts = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(parts, pad)
-    out = torch.cat([p[:n] for p, n in zip(parts, sizes)])
+    out = torch.cat([p[:n] for p, n in zip(parts, sizes)]).to(home)
     if total is not None:
         assert out.shape[0] == total
     return out

@@ -243,8 +243,11 @@ typedef struct d2d_plan {
   double half_fov;     /* math.radians(drone_view_range / 2) (yaw_planner.py:72) */
   double yaw_rate_max; /* drone_max_yaw_speed (yaw_planner.py:127) */
   double vmax_sq;      /* the largest double s with sqrt(s) < vmax: `norm(v) < vmax` (traj_planner.py:172) as `v.v <= vmax_sq` without a
-                          square root per primitive (sqrt is correctly rounded, hence monotone); 0 = the library finds it at every search */
-  double goal_sq;      /* the largest double s with sqrt(s) <= goal_tol (traj_planner.py:158), same use; 0 = as above (ABI 7) */
+                          square root per primitive (sqrt is correctly rounded, hence monotone).  Three states: 0 = the library finds it
+                          at every search; -1.0 = "nothing passes", the value for vmax <= 0; else it must BE that threshold of `vmax` --
+                          every plugin entry point checks and returns -1 on a mismatch (a stale value would silently change searches) */
+  double goal_sq;      /* the largest double s with sqrt(s) <= goal_tol (traj_planner.py:158), same use; 0 = as above, else checked
+                          against `goal_tol` in the same way (ABI 7) */
   int64_t acos_key_lo;
   uint64_t acos_mask;
   /* ---- constant tables (read only) ---- */

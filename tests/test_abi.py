@@ -83,6 +83,39 @@ def test_argument_validation_without_gpu(pkg):
     assert fn['plan_stage'](C.byref(c), C.byref(s), None, None) == -1        # null state pointers are refused first
 
 
+def test_stale_squared_thresholds_are_refused_without_gpu(pkg):
+    """d2d_plan.vmax_sq / goal_sq are redundant with vmax / goal_tol and the search trusts them: a value that is not THE threshold
+    (a plan struct re-used after vmax changed, say) is refused before any launch.  Pointers are dummies: nothing is dereferenced."""
+    import ctypes as C
+    import math
+    from drone2d_amd import _lib, host_init, device_plugins
+    A = pkg._abi
+    _, fn = _lib.load_library()
+    p = pkg.with_defaults(pkg.Params(planner='Primitive', gaze_method='Oxford', agent_number=10, agent_radius=15,
+                                     agent_max_speed=20, drone_max_speed=40, map_id=1))
+    cfg = host_init.derive_cfg(p, B=4, N=10, T=1, planner_mode=A.PLANNER_EXTERNAL, kf_enabled=True)
+    st = A.State()
+    for name, typ in A.State._fields_:
+        setattr(st, name, 1)
+    sc, _ = device_plugins.build_tables(p, cfg)
+    plan = A.Plan()
+    for name in A.PLAN_TABLES + A.PLAN_STATE:
+        setattr(plan, name, 1)
+    for k, v in sc.items():
+        setattr(plan, k, v)
+    plan.planner, plan.gaze = A.PLAN_PRIMITIVE, A.GAZE_NONE
+    good = plan.vmax_sq
+    assert math.sqrt(good) < 40.0 <= math.sqrt(math.nextafter(good, math.inf))
+    for bad in (1600.0, math.nextafter(good, 0.0), -1.0, 900.0):
+        plan.vmax_sq = bad
+        assert fn['plan_stage'](C.byref(cfg), C.byref(st), C.byref(plan), None) == -1 and b'vmax_sq' in fn['last_error'](), bad
+    plan.vmax_sq = good
+    plan.goal_sq = 100.0 - 1e-9
+    assert fn['plan_stage'](C.byref(cfg), C.byref(st), C.byref(plan), None) == -1 and b'goal_sq' in fn['last_error']()
+    plan.goal_sq, plan.vmax, plan.vmax_sq = 0.0, 0.0, 1600.0       # vmax <= 0: only -1 ("nothing passes") or 0 are accepted
+    assert fn['plan_stage'](C.byref(cfg), C.byref(st), C.byref(plan), None) == -1 and b'vmax_sq' in fn['last_error']()
+
+
 def test_oracle_exports_the_same_surface(pkg, oracle):
     for n in pkg._abi.ENTRY_POINTS:
         assert hasattr(oracle.lib, 'd2d_oracle_' + n)

@@ -182,3 +182,22 @@ def test_bench_refuses_a_world_size_that_contradicts_gpus():
                           '--warmup', '1', '--envs', '2', '--workers', '0', '--leg', 'closed', '--no-cpu-baseline'],
                          capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
     assert out.returncode != 0 and 'WORLD_SIZE' in out.stderr
+
+
+def test_bench_parent_returns_when_one_rank_dies_early(tmp_path):
+    """A rank other than 0 that dies before its first collective must not leave rank 0 -- and the parent -- waiting for the
+    collective's timeout: the parent polls every child, stops the others and fails at once."""
+    import subprocess
+    import time
+    entry = tmp_path / 'rank.py'
+    entry.write_text('import os, sys, time\n'
+                     'if os.environ["RANK"] == "1":\n'
+                     '    sys.exit(7)\n'
+                     'time.sleep(600)\n')
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    env['D2D_BENCH_ENTRY'] = str(entry)
+    t0 = time.time()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2'], capture_output=True, text=True, timeout=120,
+                         env=env, cwd=ROOT)
+    assert out.returncode == 1 and time.time() - t0 < 60, (out.returncode, out.stderr[-500:])
+    assert 'rank exit codes' in out.stderr

@@ -88,6 +88,11 @@ CASES = [
     # again) -- the level-by-level additions of the gaze stage, not its butterfly
     dict(B=6, T=80, chunk=8, agent_number=8, agent_radius=10, agent_max_speed=20, map_id=21, map_size=[520, 400],
          init_pos=[60, 60], target_list=[[460, 340], [60, 340]]),
+    # 100 x 100 cells with a view 15 cells deep: a view box of 35 cells a side is more than the sparse pairwise path holds (two blocks
+    # per box row, 64 in all) -- such a configuration takes the DENSE plan of the whole map (128 blocks) although the map has more
+    # than 4096 cells (round 3 refused it with -4)
+    dict(B=4, T=40, chunk=8, agent_number=12, agent_radius=12, agent_max_speed=30, map_id=33, map_size=[1000, 1000],
+         drone_view_depth=150, drone_view_range=100, init_pos=[300, 300], target_list=[[800, 800]]),
     # 40 x 30 = 1200 cells: a perfect tree of 16 blocks (half the butterfly's lanes hold +0.0)
     dict(B=6, T=80, chunk=8, agent_number=6, agent_radius=10, agent_max_speed=20, map_id=22, map_size=[400, 300],
          init_pos=[50, 50], target_list=[[340, 240], [60, 240]]),
@@ -290,3 +295,48 @@ def test_config5_closed_loop_vs_oracle(pkg, hip, oracle, layout):
     finally:
         oracle.lib.d2d_oracle_set_threads(1)
     assert int(ref.plugins.t['plan_stat'][:, 0].sum()) >= 4 and tracked > 0   # searches ran, trackers were active on the way
+
+
+def test_config5_closed_loop_at_shard_scale(pkg, hip):
+    """BASELINE config 5 with Oxford + Primitive on the device at ONE GPU's shard of the 262144-env job: 32768 envs x 100 agents on
+    640 x 640 cells.  The plugin state is large there -- `seen_step` [B][640][640] int32 = 53.7 GB, 238 KB of search nodes per env,
+    26.8 GB of grids (twice with the reset snapshot) -- so a 32-bit offset anywhere in the plugin stages would show exactly here.
+    4 worlds tiled, drones started next to agents of their worlds (trackers, replans, searches), 8 closed-loop steps with auto
+    reset: every env equals the 4-env run in env state AND plugin state."""
+    from drone2d_amd import vec_env
+    from drone2d_amd import _abi as A
+    from test_gpu_vs_oracle import CFG5
+    B = 32768
+    free = torch.cuda.mem_get_info()[0]
+    if free < 150 << 30:
+        pytest.skip(f'needs 150 GB of free device memory, {free >> 30} GB are free')
+    p = pkg.Params(planner='Primitive', gaze_method='Oxford', drone_max_speed=40, map_id=5, **CFG5)
+    from drone2d_amd import host_init
+    worlds = [host_init.init_world(pkg.with_defaults(_with_map(p, 5 + i))) for i in range(4)]
+    small = vec_env.VecDrone2DEnv(p, 4, backend=hip, planner='Primitive', device_plugins=True, gaze='Oxford', worlds=worlds)
+    big = vec_env.VecDrone2DEnv(p, B, backend=hip, planner='Primitive', device_plugins=True, gaze='Oxford',
+                                worlds=[worlds[i % 4] for i in range(B)])
+    assert big.plugins.t['seen_step'].numel() * 4 > 2 ** 35 and big.state.gt.numel() > 2 ** 33
+    ag = small.state.agents
+    xy = torch.stack([ag[:, A.A_PX, 7].floor() + 6.0, ag[:, A.A_PY, 7].floor() - 45.0], dim=1).clamp(40.0, 6360.0)
+    xy[0] = torch.tensor([3200., 3200.], device=xy.device)
+    small.state.drone[:, :2] = xy
+    big.state.drone[:, :2] = xy.repeat(B // 4, 1)
+    for _ in range(2):
+        big.closed_loop(4, auto_reset=True)
+        small.closed_loop(4, auto_reset=True)
+    big.sync()
+    small.sync()
+
+    def same(x, y, name):
+        for c0 in range(0, B, 2048):                      # in slices: comparing a 53.7 GB field whole would allocate 13 GB of bools
+            xs = x[c0:c0 + 2048]
+            assert bool((xs.view(xs.shape[0] // 4, 4, *x.shape[1:]) == y.unsqueeze(0)).all()), f'{name}: envs {c0}..'
+    for name in FIELDS + ('action', 'plan_ok', 'wp_valid', 'wp'):
+        same(big.state.t[name], small.state.t[name], name)
+    for name in PLUGIN_FIELDS + ('traj', 'plan_stat'):
+        same(big.plugins.t[name], small.plugins.t[name], name)
+    assert int(small.plugins.t['plan_stat'][:, 0].sum()) >= 4 and int(small.state.active.sum()) > 0   # searches ran, trackers are active
+    assert int(big.plugins.t['plan_stat'][:, 3].sum()) == 0
+    del big
+    torch.cuda.empty_cache()
