@@ -284,12 +284,88 @@ def large_batch_legs(torch, clock, pkg, vec_env, params, worlds, rank, BL, chunk
                           'roofline': roofline('k_closed', dict(shape, persistent=True), algo, BL, K / nl, us / nl)}
     us, reps = stage_leg(torch, clock, env, params, rank, BL, 'raycast', K=200, Wm=40)
     out['raycast_stage'] = {'env_steps_per_s': BL / (us * 1e-6), 'repetitions_us': reps,
-                            'roofline': roofline('raycast_stage', shape, algo_bytes(env.cfg, env.state.agent_unit, 'raycast'), BL, 1, us)}
+                            'roofline': roofline('raycast_stage', shape, algo_bytes(env.cfg, env.state.agent_unit, 'raycast'), BL, 1, us),
+                            'valu': valu('raycast_stage', shape, BL / (us * 1e-6))}
     del env
     env = vec_env.VecDrone2DEnv(params, BL, device=clock.device, planner='external', worlds=tiled)
     us, reps = stage_leg(torch, clock, env, params, rank, BL, 'step', K=200, Wm=40)
     out['step_kernel'] = {'env_steps_per_s': BL / (us * 1e-6), 'repetitions_us': reps, 'roofline': roofline('k_stages', shape, algo, BL, 1, us)}
     return out
+
+
+def survivability_bench(args):
+    """SURVEY 8(f) f4, the reference's own batched consumer of the pure hot path, end to end on one MI355X: the whole table of
+    script/difficulty_calculator/glob_survivability_calculator.py:44-57 -- 20 maps x 27 settings x 8 x 8 start cells x 240 steps =
+    8.3 M env-steps -- through sweeps.survivability_table (every (setting, start cell) one env, the 240 steps of a batch one
+    d2d_rollout call = 240 k_stages launches per stream).  `value` = env-steps / device time with the worlds resident in HBM; the
+    host's share (building 540 seeded worlds, unpacking the flags into the reference's array) is reported beside it.  The table
+    of map 0 is checked against the CPU oracle's, which is also the cpu_baseline."""
+    import numpy as np
+    import torch
+    import drone2d_amd as pkg
+    from drone2d_amd import sweeps, _lib
+    hip = _lib.HipBackend('cuda:0')
+    device = str(hip.device)                 # (a CPU backend injected by the tests' dry-run harness reports 'cpu')
+    maps = list(range(args.maps))
+    sweeps.survivability_table(map_ids=[0], agent_numbers=(10, 20, 30), agent_sizes=(10,), agent_speeds=(40,), T=1.0,
+                               device=device, backend=hip)                       # warm-up: modules loaded, allocator primed
+    t = {}
+    w0 = time.perf_counter()
+    table = sweeps.survivability_table(map_ids=maps, device=device, backend=hip, timings=t)
+    wall = time.perf_counter() - w0
+    # the kernel's own average launch time, per agent count, on ONE stream with HIP events (the rollout above runs two half-batches
+    # on two free-running streams, whose launches overlap: its time / launches is not a kernel duration)
+    per_n = []
+    for rec in t['batches']:
+        t1 = {}
+        sel = dict(map_ids=maps, agent_numbers=(rec['N'],), device=device, backend=hip, timings=t1, streams=1)
+        sweeps.survivability_table(**sel)
+        env = t1['last_env']
+        algo = algo_bytes(env.cfg, env.state.agent_unit)
+        launch_us = t1['device_s'] * 1e6 / t1['launches']
+        per_n.append({'agents': rec['N'], 'envs_per_launch': rec['envs'], 'launches': t1['launches'], 'launch_us_one_stream': launch_us,
+                      'algo_bytes_per_env_step': algo, 'achieved_GBs': algo * rec['envs'] / (launch_us * 1e-6) / 1e9,
+                      'device_s_two_streams': rec['device_s'], 'device_s_one_stream': t1['device_s']})
+        del t1['last_env']
+    algo_total = sum(r['algo_bytes_per_env_step'] * r['envs_per_launch'] * 240 for r in per_n)
+    achieved = algo_total / t['device_s'] / 1e9
+    dom = max(per_n, key=lambda r: r['device_s_two_streams'])
+    line = {'metric': 'env-steps/sec (survivability table: glob_survivability_calculator.py, NoMove / NoControl, drone pinned per start cell)',
+            'value': t['env_steps'] / t['device_s'], 'unit': 'env-steps/s', 'n_gpus': 1, 'steps': 240, 'warmup': 0,
+            'ms_per_step': t['device_s'] * 1e3 / (240 * len(t['batches'])), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': f'f4 survivability table: {len(maps)} maps x 27 settings (agents 10/20/30 x size 5/10/15 x speed 20/40/60) x '
+                                   f'8 x 8 start cells x 240 steps = {t["env_steps"]} env-steps; one batch per agent count '
+                                   f'({t["batches"][0]["envs"]} envs), two half-batches on two streams',
+                       'name': 'survivability', 'table_shape': list(table.shape), 'collisions_recorded': int(table.sum())},
+            'end_to_end': {'wall_s': wall, 'host_build_s': t['build_s'], 'device_s': t['device_s'], 'host_post_s': t['post_s'],
+                           'env_steps_per_s_wall': t['env_steps'] / wall},
+            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
+                         'traffic': None, 'kernel': 'k_stages (fused Drone2DEnv2.step; d2d_rollout = one launch per step per stream)',
+                         'note': 'achieved = algorithmic bytes (SURVEY 8(d), per agent count) of all launches / device time of the table; '
+                                 'per agent count: the kernel\'s average launch time on one stream (synchronised wall clock around the 240 queued launches)',
+                         'dominant_batch': dom, 'per_agent_count': per_n},
+            }
+    if not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, 'tests'))
+        from oracle_lib import OracleBackend
+        ob = OracleBackend()
+        threads = max(1, min(host_cores(), 32))
+        ob.lib.d2d_oracle_set_threads(threads)
+        c0 = time.perf_counter()
+        ref = sweeps.survivability_table(map_ids=[0], device='cpu', backend=ob)
+        cs = time.perf_counter() - c0
+        ob.lib.d2d_oracle_set_threads(1)
+        same = bool(np.array_equal(ref, table[:27]))
+        line['cpu_baseline'] = {'value': 27 * 64 * 240 / cs, 'unit': 'env-steps/s', 'cores': threads, 'kind': 'port',
+                                'sample': f'oracle/d2d_oracle.c, the 27 settings of map 0 (414720 env-steps) incl. host world construction, '
+                                          f'{cs:.1f} s on {threads} threads; the reference\'s Python: 12.3 ms per env.step (SURVEY 8a)',
+                                'table_of_map_0_equals_oracle': same}
+        if not same:
+            print(json.dumps(line), flush=True)
+            sys.exit('bench.py: the survivability table of map 0 differs from the oracle\'s')
+    print(json.dumps(line), flush=True)
+    return 0
 
 
 def launch_ranks(n):
@@ -368,7 +444,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=300)
     ap.add_argument('--prologue', type=int, default=300,
                     help='untimed steps before the warm-up: the timed window then sees steady-state episodes whatever --warmup is')
-    ap.add_argument('--workload', default='config2', choices=sorted(WORKLOADS))
+    ap.add_argument('--workload', default='config2', choices=sorted(WORKLOADS) + ['survivability'])
+    ap.add_argument('--maps', type=int, default=20, help='--workload survivability: map ids 0..maps-1 (the reference\'s table: 20)')
     ap.add_argument('--envs', type=int, default=0, help='envs per GPU (default: the workload\'s)')
     ap.add_argument('--leg', default='all', choices=['all', 'closed', 'step', 'raycast'],
                     help='closed: only the timed region; step / raycast: only that k_stages leg (profiler runs)')
@@ -393,6 +470,10 @@ def main():
 
     if args.gpus < 1:
         ap.error('--gpus must be >= 1')
+    if args.workload == 'survivability':
+        if args.gpus != 1:
+            ap.error('--workload survivability is a one-GPU job')
+        sys.exit(survivability_bench(args))
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
         # plain `python bench.py --gpus N`: this process only starts the N ranks (nothing here has touched the GPU)
         sys.exit(launch_ranks(args.gpus))
@@ -568,7 +649,8 @@ def main():
                 'state': 'the worlds as the flight above left them (drones spread over their maps, explored maps part filled)',
                 'launches': 500, 'repetitions_us': reps, 'env_steps_per_s': B / (us * 1e-6),
                 'roofline': roofline('raycast_stage', sshape, rb, B, 1, us,
-                                     {'note': 'bytes: 36 N agents + N hit mask + R S ground-truth reads + R (S - 1) drone-map writes + 44 B pose'})}
+                                     {'note': 'bytes: 36 N agents + N hit mask + R S ground-truth reads + R (S - 1) drone-map writes + 44 B pose'}),
+                'valu': valu('raycast_stage', sshape, B / (us * 1e-6))}
         if args.large and world == 1 and args.leg == 'all' and closed and use_cuda:
             line['large_batch'] = large_batch_legs(torch, clock, pkg, vec_env, params, worlds, rank, args.large, args.chunk, args.workload)
         if not args.no_cpu_baseline and world == 1 and args.leg == 'all':

@@ -35,10 +35,15 @@ def start_cells(params, position_step=60):
     return xs, ys
 
 
-def survivability_batch(indices, position_step=60, T=24, device='cuda:0', backend=None):
+def survivability_batch(indices, position_step=60, T=24, device='cuda:0', backend=None, timings=None, streams=None):
     """Collision states of several settings that share agent_number (same N), one launch.
     Returns float64 [len(indices), len(x_range), len(y_range), n_steps] with 1 where the drone pinned at that
-    start cell is in dynamic collision at that step (collision_flag == 2)."""
+    start cell is in dynamic collision at that step (collision_flag == 2).
+    `timings`: a dict that collects, per call, the seconds spent building the worlds on the host (`build_s`), in the T-step
+    rollout on the device with everything resident (`device_s`, synchronised on both sides) and in the host post-processing
+    (`post_s`), with `env_steps` and `launches` (bench.py --workload survivability)."""
+    import time
+    t_build = time.perf_counter()
     plist = [_params(ix) for ix in indices]
     xs, ys = start_cells(plist[0], position_step)
     cells = [(x, y) for x in xs for y in ys]
@@ -50,9 +55,14 @@ def survivability_batch(indices, position_step=60, T=24, device='cuda:0', backen
         pins += cells
     env = VecDrone2DEnv(plist[0], len(worlds), device=device, backend=backend, planner='NoMove', worlds=worlds)
     actions = torch.zeros((n_steps, len(worlds)), dtype=torch.float64, device=env.device)
-    coll = env.rollout(actions, pin=np.asarray(pins, dtype=np.float64), collisions=True,
-                       streams=2 if len(worlds) >= 1024 else 1)
+    pin = torch.as_tensor(np.asarray(pins, dtype=np.float64), device=env.device)
+    ns = streams if streams is not None else (2 if len(worlds) >= 1024 else 1)
+    if timings is not None:
+        env.sync()
+    t_dev = time.perf_counter()
+    coll = env.rollout(actions, pin=pin, collisions=True, streams=ns)
     env.sync()
+    t_post = time.perf_counter()
     hit = (coll == 2).T.reshape(len(plist), len(xs), len(ys), n_steps).cpu().numpy()
     # The reference files step k under int(t / 0.1) with t = np.arange(0, T, 0.1)[k] (:38-39).  That is not
     # always k (4.3 / 0.1 == 42.999...), so some steps share a slot and some slots are never written;
@@ -61,6 +71,13 @@ def survivability_batch(indices, position_step=60, T=24, device='cuda:0', backen
     out = np.zeros(hit.shape, dtype=np.float64)
     for k, sl in enumerate(slot):
         out[..., sl] = np.maximum(out[..., sl], hit[..., k])
+    if timings is not None:
+        rec = dict(N=int(env.cfg.N), envs=len(worlds), steps=n_steps, streams=ns, build_s=t_dev - t_build, device_s=t_post - t_dev,
+                   post_s=time.perf_counter() - t_post, env_steps=len(worlds) * n_steps, launches=n_steps * ns)
+        timings.setdefault('batches', []).append(rec)
+        for k in ('build_s', 'device_s', 'post_s', 'env_steps', 'launches'):
+            timings[k] = timings.get(k, 0) + rec[k]
+        timings['last_env'] = env        # (bench.py reads the configuration and the cells per agent of the last batch)
     return out
 
 
@@ -70,7 +87,7 @@ def survivability(index, position_step=60, T=24, device='cuda:0', backend=None):
 
 
 def survivability_table(map_ids=range(20), agent_numbers=(10, 20, 30), agent_sizes=(5, 10, 15),
-                        agent_speeds=(20, 40, 60), position_step=60, T=24, device='cuda:0', backend=None):
+                        agent_speeds=(20, 40, 60), position_step=60, T=24, device='cuda:0', backend=None, timings=None, streams=None):
     """The array the reference saves as collision_states_*.npy (glob_survivability_calculator.py:44-57), in its
     loop order: map_id outermost, then product(agent_num, agent_size, agent_vel)."""
     order = [dict(motion_profile='CVM', pillar_number=0, agent_number=n, agent_speed=v, agent_size=r, map_id=m)
@@ -78,7 +95,7 @@ def survivability_table(map_ids=range(20), agent_numbers=(10, 20, 30), agent_siz
     result = [None] * len(order)
     for n in agent_numbers:                    # one batch per agent count (a batch shares N)
         sel = [i for i, ix in enumerate(order) if ix['agent_number'] == n]
-        got = survivability_batch([order[i] for i in sel], position_step, T, device, backend)
+        got = survivability_batch([order[i] for i in sel], position_step, T, device, backend, timings, streams)
         for i, g in zip(sel, got):
             result[i] = g
     return np.array(result)

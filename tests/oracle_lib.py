@@ -9,6 +9,8 @@ ORACLE_DIR = os.path.join(ROOT, 'oracle')
 
 
 def build_oracle():
+    if os.environ.get('D2D_ORACLE_LIB'):     # another build of the restatement, e.g. `make -C oracle asan` (see oracle/Makefile)
+        return os.path.abspath(os.environ['D2D_ORACLE_LIB'])
     so = os.path.join(ORACLE_DIR, 'liboracle.so')
     src = os.path.join(ORACLE_DIR, 'd2d_oracle.c')
     hdr = os.path.join(ROOT, 'include', 'd2d.h')

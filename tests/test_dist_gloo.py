@@ -201,3 +201,17 @@ def test_bench_parent_returns_when_one_rank_dies_early(tmp_path):
                          env=env, cwd=ROOT)
     assert out.returncode == 1 and time.time() - t0 < 60, (out.returncode, out.stderr[-500:])
     assert 'rank exit codes' in out.stderr
+
+
+def test_bench_survivability_workload_dry_run():
+    """`bench.py --workload survivability` (the reference's survivability table end to end) on the CPU harness: one
+    map, the line carries `roofline` per agent count and a cpu_baseline whose table equals the timed one."""
+    import json
+    import subprocess
+    cmd = [sys.executable, os.path.join(ROOT, 'tests', 'bench_dry_rank.py'), '--workload', 'survivability', '--maps', '1']
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    j = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1])
+    assert j['config']['table_shape'] == [27, 8, 8, 240] and j['value'] > 0 and j['cpu_baseline']['table_of_map_0_equals_oracle']
+    assert [r['agents'] for r in j['roofline']['per_agent_count']] == [10, 20, 30] and j['roofline']['frac'] > 0
