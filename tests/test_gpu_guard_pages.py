@@ -27,7 +27,6 @@ CASES = [
     ('kf', 'state', dict(agent_number=50, agent_radius=10, agent_max_speed=40, static_map='maps/random_map_0.npy')),   # SPEC 3 (172 agents)
     ('agents', 'state', dict(agent_number=50, agent_radius=10, agent_max_speed=40, static_map='maps/random_map_0.npy')),
     ('kf_len', 'state', dict(agent_number=32, agent_radius=8, agent_max_speed=30)),
-    ('active', 'state', dict(agent_number=32, agent_radius=8, agent_max_speed=30)),
     ('nodes', 'plugins', DEFAULT),
     ('hash', 'plugins', DEFAULT),
     ('traj', 'plugins', DEFAULT),
@@ -37,7 +36,6 @@ CASES = [
                          target_list=[[580, 260]])),
     ('dmap', 'state', dict(agent_number=10, agent_radius=15, agent_max_speed=20, map_size=[640, 320], init_pos=[50, 50],
                            target_list=[[580, 260]])),
-    ('obs_local', 'state', DEFAULT),
 ]
 
 
@@ -66,16 +64,27 @@ def test_buffer_ending_on_a_page_boundary(pkg, hip, buf, where, kw):
     per_env = t4.numel() * t4.element_size() // 4
     b0 = PAGE // math.gcd(per_env, PAGE)                  # envs per whole number of pages
     b0 = b0 * 4 // math.gcd(b0, 4)                        # ... and a whole number of replicas of the 4 worlds
-    B = b0 * max(1, -(-(12 << 20) // (per_env * b0)))     # >= 12 MiB: the caching allocator gives such a tensor a segment of its own
-    if B > 131072:
+    B = b0 * max(1, -(-(24 << 20) // (per_env * b0)))     # >= 24 MiB: more than the remainder of any of the caching allocator's 20 MiB segments
+    if B > 200000:
         pytest.skip(f'{buf}: {per_env} B per env needs {B} envs for whole pages')
-    torch.cuda.empty_cache()                              # no cached block to carve the buffer from: it gets a fresh allocation
     big = mk(B, [worlds[i % 4] for i in range(B)])
-    tb = (big.state.t if where == 'state' else big.plugins.t)[buf]
+    # the buffer moves into an allocation of its own: with no cached block to carve it from, a tensor of whole pages (>= 10 MiB) is
+    # one fresh device allocation of exactly its size, so its last byte is the allocation's last byte
+    holder = big.state.t if where == 'state' else big.plugins.t
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    plugs = []                                            # (free remainders of partly used segments are plugged first)
+    for _ in range(32):
+        tb = torch.empty_like(holder[buf])
+        if _ends_its_allocation(tb):
+            break
+        plugs.append(tb)
+    tb.copy_(holder[buf])
+    holder[buf] = tb
+    big._st, big._plan = big.state.struct(), big.plugins.struct()
     nbytes = tb.numel() * tb.element_size()
     assert nbytes == per_env * B and nbytes % PAGE == 0
-    if not _ends_its_allocation(tb):
-        pytest.skip(f'{buf}: the allocator placed the buffer inside a larger segment')
+    assert _ends_its_allocation(tb), f'{buf}: the allocator placed the buffer inside a larger segment'
     # drones next to an agent of their world, looking at it: rays hit, trackers start, the planner has something to avoid
     ag = small.state.agents
     pin = torch.stack([ag[:, 0, 3].floor() + 8.0, ag[:, 1, 3].floor() - 40.0], dim=1)

@@ -1,5 +1,4 @@
 set -e
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout -k 10 900 python -m pytest tests -m gpu -x -q --durations=25 > gpurun_out/r4_gputest2.log 2>&1 || { tail -40 gpurun_out/r4_gputest2.log; exit 1; }
-tail -40 gpurun_out/r4_gputest2.log
+python -m pytest tests/test_gpu_guard_pages.py -m gpu -q -rs --durations=5 2>&1 | tail -15
