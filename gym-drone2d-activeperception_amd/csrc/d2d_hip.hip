@@ -2292,13 +2292,44 @@ __device__ __forceinline__ ArgsPtr uniform_ptr(const ClosedArgs *p) {
   return (ArgsPtr)(((unsigned long long)hi << 32) | lo);
 }
 
+// What a phase starts from: the bundle's address, the env index, the LDS offset of the wave -- wave-uniform by construction, said so
+// with readfirstlane -- and the lane index.  A phase that is INLINED into the persistent kernel (D2D_PH_INLINE / the search) launders
+// them through an empty asm: nothing it computes is then loop-invariant in the caller's step loop (hoisted out of the loop, such
+// values stay live across the other phases and spill), and every phase keeps the live ranges it has as a function of its own.
+struct PhaseIn {
+  ArgsPtr a;
+  int e, off, lane;
+};
+template <bool LAUNDER>
+__device__ __forceinline__ PhaseIn phase_enter(const ClosedArgs *ap, int e_, int lds_off_) {
+  const unsigned long long v = (unsigned long long)ap;
+  unsigned int lo = __builtin_amdgcn_readfirstlane((unsigned int)v), hi = __builtin_amdgcn_readfirstlane((unsigned int)(v >> 32));
+  int e = __builtin_amdgcn_readfirstlane(e_), off = __builtin_amdgcn_readfirstlane(lds_off_);
+  int lane = threadIdx.x & (WAVE - 1);
+  if constexpr (LAUNDER) asm volatile("; phase" : "+s"(lo), "+s"(hi), "+s"(e), "+s"(off), "+v"(lane));
+  PhaseIn in;
+  in.a = (ArgsPtr)(((unsigned long long)hi << 32) | lo);
+  in.e = e;
+  in.off = off;
+  in.lane = lane;
+  return in;
+}
+#ifdef D2D_PH_INLINE
+#define D2D_PH_ATTR __forceinline__
+constexpr bool kPhaseLaunder = true;
+#else
+#define D2D_PH_ATTR __attribute__((noinline))
+constexpr bool kPhaseLaunder = false;
+#endif
+
 // The planner stage as two calls: the part every step runs (small: few registers to save), and the search, called
 // only when the trajectory is empty (a few percent of the steps).
 template <int SPEC>
-__device__ __attribute__((noinline)) int ph_plan_quick(const ClosedArgs *ap, int e_, int lds_off_) {
-  const ArgsPtr a = uniform_ptr(ap);
-  const int e = __builtin_amdgcn_readfirstlane(e_), lane = threadIdx.x & (WAVE - 1);
-  char *base = d2d_lds + __builtin_amdgcn_readfirstlane(lds_off_);
+__device__ D2D_PH_ATTR int ph_plan_quick(const ClosedArgs *ap, int e_, int lds_off_) {
+  const PhaseIn in_ = phase_enter<kPhaseLaunder>(ap, e_, lds_off_);
+  const ArgsPtr a = in_.a;
+  const int e = in_.e, lane = in_.lane;
+  char *base = d2d_lds + in_.off;
   d2d_cfg c = a->c;
   if (!spec_generic(SPEC)) spec_default_apply(c);
   if constexpr (SPEC == 1 || SPEC == 2) {  // folds the size of the search's cost mirror (search_lds_nodes)
@@ -2310,11 +2341,30 @@ __device__ __attribute__((noinline)) int ph_plan_quick(const ClosedArgs *ap, int
   return need ? 1 : 0;
 }
 
+// The search is INLINED into the persistent kernel (round 4): as a function it needs all 128 VGPRs of the kernel's budget, i.e. all
+// 48 callee-saved ones, and saved + restored them around every call -- 12 KB of scratch written and read per search, 15 KB of
+// corrected HBM traffic per env-step on BASELINE config 3 (0.42 searches per env-step) -- for a caller that keeps nothing but
+// wave-uniform values in scalar registers.  A kernel has no callee-saved registers.  What the inlined body reads (the argument
+// bundle's address, the env index, the LDS offset, the lane index) is laundered through an empty asm at the call site, so that no
+// value of the search is loop-invariant in the caller's step loop: hoisted out of it, such values stay live across the other
+// phases' calls and spill.  Same-call A/B against the called form: config 2 +3 % (600 / 300 and the driver's 20-step window),
+// config 3 +4 %, config 4 +2.4 %.  -DD2D_SEARCH_CALL builds the called form.
+#ifndef D2D_SEARCH_CALL
+#define D2D_SEARCH_INLINE 1
+#define D2D_SEARCH_ATTR __forceinline__
+#else
+#define D2D_SEARCH_ATTR __attribute__((noinline))
+#endif
 template <int SPEC>
-__device__ __attribute__((noinline)) void ph_plan_search(const ClosedArgs *ap, int e_, int lds_off_) {
-  const ArgsPtr a = uniform_ptr(ap);
-  const int e = __builtin_amdgcn_readfirstlane(e_), lane = threadIdx.x & (WAVE - 1);
-  char *base = d2d_lds + __builtin_amdgcn_readfirstlane(lds_off_);
+__device__ D2D_SEARCH_ATTR void ph_plan_search(const ClosedArgs *ap, int e_, int lds_off_) {
+#ifdef D2D_SEARCH_INLINE
+  const PhaseIn in_ = phase_enter<true>(ap, e_, lds_off_);
+#else
+  const PhaseIn in_ = phase_enter<false>(ap, e_, lds_off_);
+#endif
+  const ArgsPtr a = in_.a;
+  const int e = in_.e, lane = in_.lane;
+  char *base = d2d_lds + in_.off;
   d2d_cfg c = a->c;
   if (!spec_generic(SPEC)) spec_default_apply(c);
   if constexpr (SPEC == 1 || SPEC == 2) {  // folds the size of the search's cost mirror (search_lds_nodes)
@@ -2330,10 +2380,11 @@ __device__ __attribute__((noinline)) void ph_plan_search(const ClosedArgs *ap, i
 // round trip for the arguments, one fence fewer per step.  Returns -1 when Primitive.plan has to search (the caller runs
 // ph_plan_search and then ph_stages<ACT>), else the episode flag the collision stage wrote.
 template <int SPEC>
-__device__ __attribute__((noinline)) int ph_plan_act(const ClosedArgs *ap, int e_, int lds_off_) {
-  const ArgsPtr a = uniform_ptr(ap);
-  const int e = __builtin_amdgcn_readfirstlane(e_), lane = threadIdx.x & (WAVE - 1);
-  char *base = d2d_lds + __builtin_amdgcn_readfirstlane(lds_off_);
+__device__ D2D_PH_ATTR int ph_plan_act(const ClosedArgs *ap, int e_, int lds_off_) {
+  const PhaseIn in_ = phase_enter<kPhaseLaunder>(ap, e_, lds_off_);
+  const ArgsPtr a = in_.a;
+  const int e = in_.e, lane = in_.lane;
+  char *base = d2d_lds + in_.off;
   d2d_cfg c = a->c;
   if (!spec_generic(SPEC)) spec_default_apply(c);
   if constexpr (SPEC == 1 || SPEC == 2) {  // folds the size of the search's cost mirror (search_lds_nodes)
@@ -2368,11 +2419,13 @@ __device__ __attribute__((noinline)) int ph_plan_act(const ClosedArgs *ap, int e
 // `done_`: the env's episode flag as the caller knows it (the act phase of the step before returns it) -- no load, no round trip,
 // before the gaze stage can ask for anything else.  Returns the flag as this call's collision stage wrote it (-1: it did not run).
 template <int SPEC, uint32_t STAGES>
-__device__ __attribute__((noinline)) int ph_gaze_stages(const ClosedArgs *ap, int e_, int lds_off_, int t_, int done_) {
-  const ArgsPtr a = uniform_ptr(ap);
-  const int e = __builtin_amdgcn_readfirstlane(e_), lane = threadIdx.x & (WAVE - 1);
-  const int tstep = __builtin_amdgcn_readfirstlane(t_), known_done = __builtin_amdgcn_readfirstlane(done_);
-  char *base = d2d_lds + __builtin_amdgcn_readfirstlane(lds_off_);
+__device__ D2D_PH_ATTR int ph_gaze_stages(const ClosedArgs *ap, int e_, int lds_off_, int t_, int done_) {
+  const PhaseIn in_ = phase_enter<kPhaseLaunder>(ap, e_, lds_off_);
+  const ArgsPtr a = in_.a;
+  const int e = in_.e, lane = in_.lane;
+  int tstep = __builtin_amdgcn_readfirstlane(t_), known_done = __builtin_amdgcn_readfirstlane(done_);
+  if constexpr (kPhaseLaunder) asm volatile("; phase" : "+s"(tstep), "+s"(known_done));
+  char *base = d2d_lds + in_.off;
   d2d_cfg c = a->c;
   if (!spec_generic(SPEC)) spec_default_apply(c);
 #ifdef D2D_CHAIN_PROF
@@ -2403,10 +2456,11 @@ __device__ __attribute__((noinline)) int ph_gaze_stages(const ClosedArgs *ap, in
 }
 
 template <int SPEC, uint32_t STAGES>
-__device__ __attribute__((noinline)) int ph_stages(const ClosedArgs *ap, int e_, int lds_off_) {
-  const ArgsPtr a = uniform_ptr(ap);
-  const int e = __builtin_amdgcn_readfirstlane(e_), lane = threadIdx.x & (WAVE - 1);
-  char *base = d2d_lds + __builtin_amdgcn_readfirstlane(lds_off_);
+__device__ D2D_PH_ATTR int ph_stages(const ClosedArgs *ap, int e_, int lds_off_) {
+  const PhaseIn in_ = phase_enter<kPhaseLaunder>(ap, e_, lds_off_);
+  const ArgsPtr a = in_.a;
+  const int e = in_.e, lane = in_.lane;
+  char *base = d2d_lds + in_.off;
   d2d_cfg c = a->c;
   if (!spec_generic(SPEC)) spec_default_apply(c);
   const int wpb = (SPEC == 1 || SPEC == 2) ? WAVES_PER_BLOCK : (int)(blockDim.x / WAVE);
