@@ -2286,11 +2286,6 @@ typedef const ClosedArgs __attribute__((address_space(4))) *ArgsPtr;
 #else
 typedef const ClosedArgs *ArgsPtr;  // the host pass only parses the device functions
 #endif
-__device__ __forceinline__ ArgsPtr uniform_ptr(const ClosedArgs *p) {
-  const unsigned long long v = (unsigned long long)p;
-  const unsigned int lo = __builtin_amdgcn_readfirstlane((unsigned int)v), hi = __builtin_amdgcn_readfirstlane((unsigned int)(v >> 32));
-  return (ArgsPtr)(((unsigned long long)hi << 32) | lo);
-}
 
 // What a phase starts from: the bundle's address, the env index, the LDS offset of the wave -- wave-uniform by construction, said so
 // with readfirstlane -- and the lane index.  A phase that is INLINED into the persistent kernel (D2D_PH_INLINE / the search) launders
@@ -2314,6 +2309,17 @@ __device__ __forceinline__ PhaseIn phase_enter(const ClosedArgs *ap, int e_, int
   in.lane = lane;
   return in;
 }
+// Round 4: EVERY phase is inlined into the persistent kernel (a kernel has no callee-saved registers: as functions the phases saved
+// and restored up to 48 VGPRs per call -- 11 KB of scratch written and read per env-step in the gaze + perceive phase of the
+// many-agent kernels, 12 KB per search).  Two things make that work where rounds 1-3 measured spills: the laundering above, and
+// building WITHOUT MachineLICM (csrc/build.sh: -mllvm -disable-machine-licm) -- that pass hoists the 64-bit constants of every phase
+// (polynomial coefficients of tan / sin / cos, thresholds) to the kernel's entry, where they are live across the whole step loop;
+// a 64-bit literal is two moves and not rematerialisable, so the allocator SPILLS constants (18 at entry, ~130 reloads inside the
+// loop, and scalar ones into VGPR lanes).  Without the pass the inlined kernel has no scratch at all.  -DD2D_PH_CALLS builds the
+// called form (the search stays inlined), e.g. for A/B runs.
+#ifndef D2D_PH_CALLS
+#define D2D_PH_INLINE 1
+#endif
 #ifdef D2D_PH_INLINE
 #define D2D_PH_ATTR __forceinline__
 constexpr bool kPhaseLaunder = true;
