@@ -81,6 +81,22 @@ __device__ __forceinline__ int wave_argmin(double t, int idx) {
              min(__builtin_amdgcn_readlane(c, 47), __builtin_amdgcn_readlane(c, 63)));
 }
 
+// Minimum / maximum over the wave, returned wave-uniform (DPP row shifts + four lane reads, no LDS round trips; never NaN inputs)
+__device__ __forceinline__ double wave_fmin(double m) {
+  m = __builtin_fmin(m, row_shr_f64<1>(m));
+  m = __builtin_fmin(m, row_shr_f64<2>(m));
+  m = __builtin_fmin(m, row_shr_f64<4>(m));
+  m = __builtin_fmin(m, row_shr_f64<8>(m));
+  return __builtin_fmin(__builtin_fmin(readlane_f64(m, 15), readlane_f64(m, 31)), __builtin_fmin(readlane_f64(m, 47), readlane_f64(m, 63)));
+}
+__device__ __forceinline__ double wave_fmax(double m) {
+  m = __builtin_fmax(m, row_shr_f64<1>(m));
+  m = __builtin_fmax(m, row_shr_f64<2>(m));
+  m = __builtin_fmax(m, row_shr_f64<4>(m));
+  m = __builtin_fmax(m, row_shr_f64<8>(m));
+  return __builtin_fmax(__builtin_fmax(readlane_f64(m, 15), readlane_f64(m, 31)), __builtin_fmax(readlane_f64(m, 47), readlane_f64(m, 63)));
+}
+
 struct TrkView {  // active trackers of the env, compacted into LDS
   double *mx, *my, *vx, *vy;
   double *lim;  // norm(d) <= L rewritten as d.d <= T(L), see sq_threshold: replan_check's limits, then (when a search follows) plan's
@@ -407,10 +423,17 @@ __device__ int plan_search(const d2d_cfg &c, const d2d_state &s, const d2d_plan 
   // expansion need no de-duplication among themselves.  (u_space = arange(-a, a, 0.4 vmax - 5) or step 4: always, for drone speeds
   // of 14 and more.)
   bool nodup;
+  double amax = 0.0;  // the largest |acceleration| (for the reach bound below), from the staged copy like the spacing: lane reads +
+                      // DPP reductions instead of one dependent uniform load per acceleration (eight round trips per search)
   {
     double dmin = 1e300;
-    for (int i = lane; i + 1 < p.nu; i += WAVE) dmin = fmin(dmin, S.us[i + 1] - S.us[i]);  // (staged above, behind a hand-off)
-    for (int o = 32; o > 0; o >>= 1) dmin = fmin(dmin, shfl_f64(dmin, (lane ^ o)));
+    for (int i = lane; i < p.nu; i += WAVE) {  // (staged above, behind a hand-off)
+      const double ui = S.us[i];
+      if (i + 1 < p.nu) dmin = fmin(dmin, S.us[i + 1] - ui);
+      amax = fmax(amax, fabs(ui));
+    }
+    dmin = wave_fmin(dmin);
+    amax = wave_fmax(amax);
     nodup = H * dmin > 1.0 + 1e-6;
   }
   int nn = 1, open_n = 1, goal = -1, itr = 0, expansions = 0;
@@ -420,8 +443,6 @@ __device__ int plan_search(const d2d_cfg &c, const d2d_state &s, const d2d_plan 
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
   const FastDiv fd_nu(p.nu), fd_ns(p.n_sample);
   // |sample| <= |p| + T |v| + T^2 |a| / 2 for every sample time T < horizon: one bound per expansion instead of a test per sample
-  double amax = 0.0;
-  for (int i = 0; i < p.nu; ++i) amax = fmax(amax, fabs(p.u_space[i]));
   const double reach_a = 0.5 * H * H * amax + 2.0;
   // the pairs of one primitive never straddle two rounds of 64 when n_sample divides 64: its free samples are one bit field
   const bool ns_pow2 = (p.n_sample & (p.n_sample - 1)) == 0 && p.n_sample <= WAVE;

@@ -1,6 +1,6 @@
 set -e
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout -k 10 900 python -m pytest tests -m gpu -x -q > gpurun_out/r4_gputest3.log 2>&1 || { tail -40 gpurun_out/r4_gputest3.log; exit 1; }
-tail -4 gpurun_out/r4_gputest3.log
-D2D_RANDOM_SEEDS=300 D2D_RANDOM_BASE=2000000 timeout -k 10 600 python -m pytest tests/test_gpu_plugins_random.py -m gpu -x -q 2>&1 | tail -3
+SHAPES="c2 d c2L c4" bash tools/ab_closed.sh ab_base.so ab_s.so libd2d_hip.so 2>&1 | tee gpurun_out/r4_ab_fence2.txt
+B=1 D2D_LIB=$PWD/gym-drone2d-activeperception_amd/csrc/libd2d_hip.so python tools/lone_wave.py 2>&1 | head -2
+B=1 D2D_LIB=$PWD/gym-drone2d-activeperception_amd/csrc/ab_s.so python tools/lone_wave.py 2>&1 | head -2
