@@ -33,6 +33,7 @@
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <type_traits>
 
@@ -2411,7 +2412,7 @@ __device__ D2D_PH_ATTR int ph_plan_act(const ClosedArgs *ap, int e_, int lds_off
   in.ok = true;
   in.has_wp = true;
   in.wp[0] = w_head.x; in.wp[1] = w_head.y; in.wp[2] = w_head.z; in.wp[3] = w_head.w; in.wp[4] = 0.0; in.wp[5] = 0.0;
-  const int wpb = (SPEC == 1 || SPEC == 2) ? WAVES_PER_BLOCK : (int)(blockDim.x / WAVE);
+  const int wpb = (int)(blockDim.x / WAVE);
   const Geom g = make_geom(c, wpb, spec_ncap(SPEC), spec_full(SPEC));
   const LdsView L = carve(base, g, c.L);
   EnvRegs r;
@@ -2443,7 +2444,7 @@ __device__ D2D_PH_ATTR int ph_gaze_stages(const ClosedArgs *ap, int e_, int lds_
   D2D_PHASE_ADD(0, pp0);
   const unsigned long long pp1 = __builtin_amdgcn_s_memtime();
 #endif
-  const int wpb = (SPEC == 1 || SPEC == 2) ? WAVES_PER_BLOCK : (int)(blockDim.x / WAVE);
+  const int wpb = (int)(blockDim.x / WAVE);
   const Geom g = make_geom(c, wpb, spec_ncap(SPEC), spec_full(SPEC));
   const LdsView L = carve(base, g, c.L);
   EnvRegs r;
@@ -2469,7 +2470,7 @@ __device__ D2D_PH_ATTR int ph_stages(const ClosedArgs *ap, int e_, int lds_off_)
   char *base = d2d_lds + in_.off;
   d2d_cfg c = a->c;
   if (!spec_generic(SPEC)) spec_default_apply(c);
-  const int wpb = (SPEC == 1 || SPEC == 2) ? WAVES_PER_BLOCK : (int)(blockDim.x / WAVE);
+  const int wpb = (int)(blockDim.x / WAVE);
   const Geom g = make_geom(c, wpb, spec_ncap(SPEC), spec_full(SPEC));
   const LdsView L = carve(base, g, c.L);
   EnvRegs r;
@@ -2482,7 +2483,7 @@ __device__ D2D_PH_ATTR int ph_stages(const ClosedArgs *ap, int e_, int lds_off_)
 template <int SPEC>
 __global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK, D2D_MIN_WAVES) void k_closed(const ClosedArgs *__restrict__ a) {
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);
-  const int wpb = (SPEC == 1 || SPEC == 2) ? WAVES_PER_BLOCK : (int)(blockDim.x / WAVE);
+  const int wpb = (int)(blockDim.x / WAVE);
   const int e = blockIdx.x * wpb + wv;
   if (e >= a->c.B) return;
   d2d_cfg c = a->c;
@@ -2868,8 +2869,13 @@ int d2d_closed_loop(const d2d_cfg *c, const d2d_state *s, const d2d_plan *p, int
       return spec == 0 ? closed_wave_bytes<0>(*c, *p, wpb) : spec == 1 ? closed_wave_bytes<1>(*c, *p, wpb)
            : spec == 2 ? closed_wave_bytes<2>(*c, *p, wpb) : closed_wave_bytes<3>(*c, *p, wpb);
     };
-    const int wpb = (spec == 1 || spec == 2) ? ((size_t)bytes(WAVES_PER_BLOCK) * WAVES_PER_BLOCK <= LDS_SOFT ? WAVES_PER_BLOCK : 0)
-                                             : best_wpb(bytes);
+    // ONE wave (env) per workgroup: the waves of a workgroup never talk to each other, but a workgroup holds its wave slots and its
+    // LDS until its SLOWEST wave has finished -- and the chains of a launch differ widely (a mean chain is 0.3-0.6 of the longest:
+    // searches, resets).  With four envs per workgroup, three slots of every workgroup with a heavy env idle until it ends; with one
+    // they go to the next env at once.  Same-call, 600 / 300: config 4 (32 768 envs) 7.98e7 -> 9.35e7, config 5 2.43e7 -> 2.74e7,
+    // config 2 at 65 536 envs 1.25e8 -> 1.32e8, at 16 384 1.08e8 -> 1.14e8; at 4096 envs (one round: every env has its slot from
+    // the start) 8.44e7 = 8.42e7.  (A k_stages launch does the same work in every wave and keeps four.)
+    const int wpb = (size_t)bytes(1) <= LDS_HARD ? 1 : 0;
     if (wpb >= 1) {
       const dim3 grid((c->B + wpb - 1) / wpb), block(WAVE * wpb);
       const size_t lds = (size_t)bytes(wpb) * wpb;
@@ -2925,7 +2931,7 @@ int d2d_launch_shape(const d2d_cfg *c, const d2d_plan *p, int32_t out[4]) {
       return spec == 0 ? closed_wave_bytes<0>(*c, *p, w) : spec == 1 ? closed_wave_bytes<1>(*c, *p, w)
            : spec == 2 ? closed_wave_bytes<2>(*c, *p, w) : closed_wave_bytes<3>(*c, *p, w);
     };
-    wpb = (spec == 1 || spec == 2) ? ((size_t)bytes(WAVES_PER_BLOCK) * WAVES_PER_BLOCK <= LDS_SOFT ? WAVES_PER_BLOCK : 0) : best_wpb(bytes);
+    wpb = (size_t)bytes(1) <= LDS_HARD ? 1 : 0;   // the persistent kernel runs one env per workgroup (d2d_closed_loop)
     wb = wpb >= 1 ? (size_t)bytes(wpb) : 0;
     if (!p->launch_args || c->planner_mode != D2D_PLANNER_EXTERNAL) wpb = 0;
   }

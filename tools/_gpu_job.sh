@@ -1,6 +1,8 @@
 set -e
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-SHAPES="c2 d c2L c4" bash tools/ab_closed.sh ab_base.so ab_s.so libd2d_hip.so 2>&1 | tee gpurun_out/r4_ab_fence2.txt
-B=1 D2D_LIB=$PWD/gym-drone2d-activeperception_amd/csrc/libd2d_hip.so python tools/lone_wave.py 2>&1 | head -2
-B=1 D2D_LIB=$PWD/gym-drone2d-activeperception_amd/csrc/ab_s.so python tools/lone_wave.py 2>&1 | head -2
+python -m pytest tests/test_gpu_plugins.py -m gpu -x -q 2>&1 | tail -2
+run() { python bench.py --no-cpu-baseline --leg closed --large 0 --workers 8 "$@" 2>/dev/null | tail -1 | python -c "import sys,json; print('%.4e' % json.loads(sys.stdin.read())['value'])"; }
+for ch in 150 300 600 1200; do
+  echo "chunk $ch: c4 $(run --steps 1200 --warmup 300 --chunk $ch --workload config4 --distinct-worlds 512)  c2L $(run --steps 1200 --warmup 300 --chunk $ch --envs 65536 --distinct-worlds 4096) c2 $(run --steps 1200 --warmup 300 --chunk $ch)"
+done

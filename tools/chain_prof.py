@@ -14,8 +14,13 @@ from drone2d_amd import vec_env
 
 B = int(os.environ.get('B', 4096))
 STEPS = int(os.environ.get('STEPS', 300))
-p = pkg.Params(planner='Primitive', gaze_method='Oxford', agent_number=10, agent_radius=15, agent_max_speed=20, drone_max_speed=40, map_id=1)
-env = vec_env.VecDrone2DEnv(p, B, planner='Primitive', device_plugins=True, gaze='Oxford')
+# WORKLOAD=config3|config4|config5: bench.py's table (WORLDS distinct seeded worlds tiled over the batch)
+import bench
+WL = os.environ.get('WORKLOAD', 'config2')
+NW = min(B, int(os.environ.get('WORLDS', 512 if WL != 'config2' else B)))
+p = pkg.Params(planner='Primitive', gaze_method='Oxford', drone_max_speed=40, map_id=1, **bench.WORKLOADS[WL][1])
+worlds = vec_env.build_worlds(p, NW, workers=0)
+env = vec_env.VecDrone2DEnv(p, B, planner='Primitive', device_plugins=True, gaze='Oxford', worlds=[worlds[i % NW] for i in range(B)])
 env.closed_loop(300, auto_reset=True)
 torch.cuda.synchronize()
 import ctypes as C
