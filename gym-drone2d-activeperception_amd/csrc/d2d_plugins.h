@@ -1455,6 +1455,9 @@ __device__ __forceinline__ void gaze_env(const d2d_cfg &c, const d2d_state &s, c
   return;
 #endif
   GZ(3);  // live-cell compaction
+#ifndef D2D_GAZE_EXACT_ONLY
+  double qa[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};  // this lane's part of every candidate's sum, in ANY order (the quick decision below)
+#endif
   for (int l0 = 0; l0 < nlive; l0 += 4 * WAVE) {
     // four live cells per lane: their seen-map entries are fetched together, then their table rows, then the arithmetic
     int qq[4], sn[4];
@@ -1529,6 +1532,16 @@ __device__ __forceinline__ void gaze_env(const d2d_cfg &c, const d2d_state &s, c
         const bool hot = (bits != 0u) & (rw != 0.0);
         rew[q] = rw;
         cm[q] = hot ? (unsigned char)bits : (unsigned char)0;
+#ifndef D2D_GAZE_EXACT_ONLY
+        {
+          const int hbits = hot ? (int)bits : 0;
+#pragma unroll
+          for (int a = 0; a < 7; ++a) {  // + view * reward, view in {0.0, 1.0} (as in the block sums below)
+            const double view = __hiloint2double(((hbits << (31 - a)) >> 31) & 0x3ff00000, 0);
+            qa[a] = __builtin_fma(rw, view, qa[a]);
+          }
+        }
+#endif
         const unsigned int hb = hot ? 1u : 0u;
         hr0 |= r < 32 ? hb << (r & 31) : 0u;
         hr1 |= r < 32 ? 0u : hb << (r & 31);
@@ -1563,6 +1576,45 @@ __device__ __forceinline__ void gaze_env(const d2d_cfg &c, const d2d_state &s, c
     if (lane == 0) act[e] = ys_l / p.yaw_rate_max;
     return;
   }
+#ifndef D2D_GAZE_EXACT_ONLY
+  // ---- the quick decision (round 4).  The argmax over the candidates needs numpy's pairwise sums (below: a third of the stage) only
+  //      when two of them are close.  Every candidate's sum is first formed in ANY order (per-lane partial sums above, LDS atomic
+  //      adds here).  A sum of n non-negative terms carries a relative error of at most (n - 1) u in any order of addition (u = 2^-53,
+  //      n < 4096 cells of the box: below 5e-13), numpy's pairwise order included.  So a candidate more than 1e-9 M below the
+  //      largest quick sum M is STRICTLY below it in numpy's sums too -- it cannot be the argmax -- and
+  //        * one contender left (four steps in five): it is the reference's choice;
+  //        * several contenders that see exactly the same cells with a non-zero term (one step in five: neighbouring yaw rates whose
+  //          views differ only in cells the drone sees right now): their numpy sums are the same terms at the same positions,
+  //          bit-identical, and the reference's strict `<` keeps the first of them;
+  //        * anything else (3 % of the steps): the exact sums below decide, as before.
+  //      Measured on 100 000 plan() calls of the oracle's closed loop (profiles/r04/NOTES.md).  -DD2D_GAZE_EXACT_ONLY builds the
+  //      stage without this block (csrc/libd2d_hip_exact.so: the suite runs the exact path on every step through it). ----
+  {
+    double *qs = stk;  // [8]: the view directions kept there have been consumed by the reward pass
+    if (lane < 8) qs[lane] = 0.0;
+#pragma unroll
+    for (int a = 0; a < 7; ++a)
+      if (qa[a] != 0.0) atomicAdd(&qs[a], qa[a]);  // (LDS operations of one wave execute in order: behind the clear above)
+    wave_sync_lds();
+    const double q_l = qs[min(lane, 7)];
+    const bool cand = lane < p.n_yaw;
+    const double M = wave_fmax(cand ? q_l : 0.0);  // > 0: some cell carries a non-zero term
+    const unsigned int C = (unsigned int)__ballot(cand & (q_l >= M - 1e-9 * M));
+    bool bad = false;
+    if (__popc(C) > 1) {
+      for (int l = lane; l < nlive; l += WAVE) {
+        const unsigned int t = (unsigned int)cm[swl[l]] & C;
+        bad = bad | ((t != 0u) & (t != C));
+      }
+    }
+    if (!__any(bad)) {
+      const double ys_best = shfl_f64(ys_l, __ffs((int)C) - 1);
+      if (lane == 0) act[e] = ys_best / p.yaw_rate_max;  // :127
+      return;
+    }
+    wave_sync_lds();  // (the exact path re-uses `stk`)
+  }
+#endif
   // rows / columns of the grid that hold a non-zero term (they lie inside the box and inside the map)
   const int row_lo = bi + __ffsll((long long)hrows) - 1, row_hi = bi + 63 - __clzll((long long)hrows);
   const int jlo = bj + __ffsll((long long)hcols) - 1, jhi = bj + 64 - __clzll((long long)hcols);

@@ -340,3 +340,22 @@ def test_config5_closed_loop_at_shard_scale(pkg, hip):
     assert int(big.plugins.t['plan_stat'][:, 3].sum()) == 0
     del big
     torch.cuda.empty_cache()
+
+
+def test_exact_only_gaze_build(hip):
+    """The gaze stage settles four steps in five with sums formed in any order and falls back to numpy's pairwise sums only when two
+    candidates are close (d2d_plugins.h, "the quick decision").  csrc/libd2d_hip_exact.so is the same library with that block
+    compiled out: the closed-loop parity cases and the reference episodes run through it in a child process (D2D_LIB), so the exact
+    path is exercised on EVERY step, not on 3 % of them."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, 'gym-drone2d-activeperception_amd', 'csrc', 'libd2d_hip_exact.so')
+    assert os.path.isfile(lib), 'build it with __graft_entry__.build()'
+    env = dict(os.environ, D2D_LIB=lib)
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-m', 'gpu', '-q', '-x', '-k',
+                        'test_closed_loop_matches_oracle or test_hip_plugins_reproduce_the_reference_episode or test_config5_closed_loop_vs_oracle'],
+                       env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert ' passed' in r.stdout and 'skipped' not in r.stdout.splitlines()[-1], r.stdout[-500:]
