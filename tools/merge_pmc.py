@@ -10,4 +10,7 @@ main['more'] = []
 for f in sys.argv[2:]:
     d = json.load(open(f))
     main['more'].append({k: v for k, v in d.items() if isinstance(v, dict) and 'shape' in v})
+hashes = {main.get('src_hash')} | {v.get('src_hash') for m in main['more'] for v in m.values()}
+if len(hashes) != 1:
+    sys.exit(f'merge_pmc.py: the records were measured on different kernel sources: {sorted(map(str, hashes))}')
 json.dump(main, sys.stdout, indent=1)

@@ -47,11 +47,15 @@ def own_rows(leg, rows):
     return rows[len(rows) // 8:] if leg in ('raycast', 'step') else rows
 
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from src_hash import source_hash
+SRC = source_hash()      # the kernels these figures were measured on (tests/test_profiles.py checks it against the tree)
+
 res = {}
 for leg, (prefix, key, per_launch) in LEGS.items():
     if not os.path.isdir(os.path.join(out, leg)):
         continue
-    r = {'shape': {'workload': WORKLOAD, 'envs': ENVS}, 'env_steps_per_launch': per_launch,
+    r = {'shape': {'workload': WORKLOAD, 'envs': ENVS}, 'env_steps_per_launch': per_launch, 'src_hash': SRC,
          'source': f'tools/gpu_profile.sh, bench.py --leg {leg} {bench_args}'.strip()}
     if leg == 'closed' and key == 'k_closed':
         r['shape']['persistent'] = True
@@ -110,5 +114,6 @@ res['note'] = ('hbm_bytes_per_env_step = (2 x FETCH_SIZE + WRITE_SIZE) / env-ste
                'request on wide coalesced reads, MI355X_MICROARCH.md HBM section; uncalibrated for the 1- to 16-byte pieces these kernels '
                'read, so ..._raw = FETCH_SIZE + WRITE_SIZE is kept beside it and the two bracket the truth).  SQ_INSTS_* = wave-instructions; '
                'SQ_ACTIVE_INST_VALU and SQ_WAVE_CYCLES count quad-cycles, x4 = shader cycles summed over all waves.')
+res['src_hash'] = SRC
 json.dump(res, open(os.path.join(out, 'pmc_latest.json'), 'w'), indent=1)
 print('== wrote', os.path.join(out, 'pmc_latest.json'))
