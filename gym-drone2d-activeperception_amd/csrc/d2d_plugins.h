@@ -72,6 +72,9 @@ __device__ __forceinline__ int wave_argmin(double t, int idx) {
   m = __builtin_fmin(m, row_shr_f64<8>(m));
   const double wmin = __builtin_fmin(__builtin_fmin(readlane_f64(m, 15), readlane_f64(m, 31)),
                                      __builtin_fmin(readlane_f64(m, 47), readlane_f64(m, 63)));
+  // one lane holds the minimum (ties between total costs are rare): its slot is a lane read, no second reduction
+  const unsigned long long eq = __ballot(t == wmin);
+  if (__popcll(eq) == 1) return __builtin_amdgcn_readlane(idx, __ffsll((long long)eq) - 1);
   int c = (t == wmin) ? idx : 0x7fffffff;
   c = min(c, row_shr_i32<1>(c));
   c = min(c, row_shr_i32<2>(c));
