@@ -377,7 +377,9 @@ int d2d_plan_reset(const d2d_cfg *cfg, const d2d_plan *plan, const uint8_t *mask
  * out[0] = waves (envs) per workgroup, out[1] = LDS bytes per workgroup, out[2] = workgroups of that size a CU's 160 KB of
  * LDS hold, out[3] = 1 if the specialised default-geometry kernels apply (both grids staged whole in LDS), else 0.
  * `plan` == NULL: the fused step (d2d_step / d2d_run_stages); else the persistent closed loop (d2d_closed_loop), out[0] = 0
- * when it would fall back to one launch per stage.  Returns 0, or a negative error like every entry point. */
+ * when it would fall back to one launch per stage.  The persistent closed loop runs ONE env per workgroup (out[0] = 1: a workgroup
+ * holds its wave slots until its slowest env has finished its steps; a CU then holds out[2] >= 16 of them at the default
+ * geometry).  Returns 0, or a negative error like every entry point. */
 int d2d_launch_shape(const d2d_cfg *cfg, const d2d_plan *plan, int32_t out[4]);
 
 /* Device restatement of the host libm sin() / cos() the reference's math.sin / math.cos resolve to
