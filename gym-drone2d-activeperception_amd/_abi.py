@@ -2,7 +2,7 @@
 the header exactly; tests/test_abi.py cross-checks sizes and constants against the header text."""
 import ctypes as C
 
-D2D_ABI_VERSION = 7
+D2D_ABI_VERSION = 8
 
 UNEXPLORED, OCCUPIED, UNOCCUPIED, DYNAMIC = 0, 1, 2, 3
 SM_WAIT_FOR_GOAL, SM_GOAL_REACHED, SM_PLANNING, SM_EXECUTING = 0, 1, 2, 3
@@ -50,7 +50,7 @@ PLAN_INT_FIELDS = ('planner', 'gaze', 'nu', 'n_sample', 'n_ts', 'max_itr', 'traj
                    'pw_nleaf', 'pw_nprog', 'tobs_len', 'pw_ntree')
 PLAN_F64_FIELDS = ('horizon', 'vmax', 'safe_dist', 'goal_tol', 'agent_radius', 'half_fov', 'yaw_rate_max', 'vmax_sq', 'goal_sq')
 PLAN_TABLES = ('u_space', 'sample_t', 'traj_t', 'yaw_space', 'tobs_tab', 'pw_leaf', 'pw_prog', 'pw_tree', 'pw_rowleaf', 'trk_radius0')
-PLAN_STATE = ('traj', 'traj_hdr', 'trk_radius', 'trk_prev', 'trk_lim', 'seen_step', 'nodes', 'hash', 'launch_args', 'plan_stat')
+PLAN_STATE = ('traj', 'traj_hdr', 'traj_box', 'trk_radius', 'trk_prev', 'trk_lim', 'seen_step', 'nodes', 'hash', 'launch_args', 'plan_stat')
 LAUNCH_ARGS_BYTES = 2048
 
 

@@ -2386,8 +2386,10 @@ __device__ D2D_SEARCH_ATTR void ph_plan_search(const ClosedArgs *ap, int e_, int
 // planner's result reaches the control stage in registers -- no store -> fence -> load between the two, one call, one scalar-load
 // round trip for the arguments, one fence fewer per step.  Returns -1 when Primitive.plan has to search (the caller runs
 // ph_plan_search and then ph_stages<ACT>), else the episode flag the collision stage wrote.
+// `walls_ok`: the env's "every remaining waypoint passed the wall test and only rays have written the map since" flag
+// (plan_env_quick), carried by the caller across the steps of a launch.
 template <int SPEC>
-__device__ D2D_PH_ATTR int ph_plan_act(const ClosedArgs *ap, int e_, int lds_off_) {
+__device__ D2D_PH_ATTR int ph_plan_act(const ClosedArgs *ap, int e_, int lds_off_, int &walls_ok) {
   const PhaseIn in_ = phase_enter<kPhaseLaunder>(ap, e_, lds_off_);
   const ArgsPtr a = in_.a;
   const int e = in_.e, lane = in_.lane;
@@ -2399,7 +2401,10 @@ __device__ D2D_PH_ATTR int ph_plan_act(const ClosedArgs *ap, int e_, int lds_off
     __builtin_assume(c.N <= cap);
   }
   double4 w_head;
-  const bool need = plan_env_quick(c, a->s, a->p, e, lane, base, &w_head);
+  int wk = __builtin_amdgcn_readfirstlane(walls_ok);
+  if constexpr (kPhaseLaunder) asm volatile("; phase" : "+s"(wk));
+  const bool need = plan_env_quick(c, a->s, a->p, e, lane, base, &w_head, &wk);
+  walls_ok = __builtin_amdgcn_readfirstlane(wk);
   if (need) {
     wave_sync_global();
     return -1;
@@ -2493,6 +2498,7 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK, D2D_MIN_WAVES) void k_closed
   const int nsteps = a->nsteps;
   const bool freeze = a->on_done == D2D_DONE_FREEZE;
   int nsearch = 0;
+  int walls_ok = 0;  // (plan_env_quick: nothing is known about the trajectory's waypoints at the start of a launch)
 #ifdef D2D_CHAIN_PROF
   // Diagnostic build only (tools/chain_prof.py): how long this env's chain of steps ran (shader clocks) and how much of it
   // its searches took -- the launch lasts as long as the longest chain.
@@ -2515,7 +2521,7 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK, D2D_MIN_WAVES) void k_closed
       const unsigned long long q0 = __builtin_amdgcn_s_memtime();
 #endif
       // the planner's every-step part and, unless it has to search, the act phase behind it in the same call (ph_plan_act)
-      const int pa = __builtin_amdgcn_readfirstlane(ph_plan_act<SPEC>(a, e, off));
+      const int pa = __builtin_amdgcn_readfirstlane(ph_plan_act<SPEC>(a, e, off, walls_ok));
 #ifdef D2D_CHAIN_PROF
       D2D_PHASE_ADD(2, q0);  // (planner every-step part + act of the steps without a search)
 #endif
@@ -2525,6 +2531,7 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK, D2D_MIN_WAVES) void k_closed
 #endif
         ph_plan_search<SPEC>(a, e, off);
         nsearch += 1;
+        walls_ok = 0;  // a new trajectory (or none): its waypoints have not been through replan_check yet
 #ifdef D2D_CHAIN_PROF
         cps += __builtin_amdgcn_s_memtime() - s0;
         D2D_PHASE_ADD(3, s0);

@@ -230,6 +230,15 @@ __device__ __forceinline__ int meta_parent(double m) { return __double2loint(m);
 __device__ __forceinline__ int meta_itr(double m) { return __double2hiint(m) >> 2; }
 __device__ __forceinline__ int meta_state(double m) { return __double2hiint(m) & 3; }
 
+// chunks a remaining trajectory has to span before the every-step walks consult the boxes
+#ifndef D2D_TRAJ_PRUNE_CHUNKS
+#define D2D_TRAJ_PRUNE_CHUNKS 4
+#endif
+// d2d_plan.traj_box of env e, or null when the caller gave none (then every walk visits every chunk)
+__device__ __forceinline__ double *traj_boxes(const d2d_plan &p, int e) {
+  return p.traj_box ? (double *)p.traj_box + (size_t)e * ((p.traj_cap + WAVE - 1) / WAVE) * 4 : nullptr;
+}
+
 // The dict of a search in LDS: open addressing over LH_N 16-bit entries, entry = 5 fingerprint bits of the key's hash << 11 |
 // slot + 1 (0 = empty).  A key that is not in the dict -- most successors -- is settled without leaving LDS; a fingerprint match
 // is confirmed against the node's key in its record (the same load brings its cost and state).  Holds LH_MAX keys / slots below
@@ -852,8 +861,10 @@ __device__ int plan_search(const d2d_cfg &c, const d2d_state &s, const d2d_plan 
   }
   wave_sync_lds();
   const int total = depth * p.n_ts;
+  double *tbox = traj_boxes(p, e);
   for (int w0 = 0; w0 < total; w0 += WAVE) {
     const int w = w0 + lane;
+    double ox = 0.0, oy = 0.0;
     if (w < total) {
       const int lvl = w / p.n_ts, mi = w - lvl * p.n_ts;
       const int q = chain[lvl];
@@ -864,10 +875,21 @@ __device__ int plan_search(const d2d_cfg &c, const d2d_state &s, const d2d_plan 
       const double t = p.traj_t[3 * mi], t2 = p.traj_t[3 * mi + 1], tt = p.traj_t[3 * mi + 2];
       const double2 pp = ld2(nd.rec(par) + NR_POS), pv = ld2(nd.rec(par) + NR_VEL);
       double *o = traj + (size_t)w * 4;
-      o[0] = rint(__builtin_fma(t2, hx, pp.x + t * pv.x));  // :121
-      o[1] = rint(__builtin_fma(t2, hy, pp.y + t * pv.y));
+      ox = rint(__builtin_fma(t2, hx, pp.x + t * pv.x));  // :121
+      oy = rint(__builtin_fma(t2, hy, pp.y + t * pv.y));
+      o[0] = ox;
+      o[1] = oy;
       o[2] = pv.x + tt * hx;                                // :122
       o[3] = pv.y + tt * hy;
+    }
+    if (tbox) {  // the bounding box of this chunk of 64 waypoints (d2d_plan.traj_box): what lets the every-step walks skip it
+      const bool on = w < total;
+      const double xlo = wave_fmin(on ? ox : 1e300), ylo = wave_fmin(on ? oy : 1e300);
+      const double xhi = wave_fmax(on ? ox : -1e300), yhi = wave_fmax(on ? oy : -1e300);
+      if (lane == 0) {
+        st2(tbox + 4 * (w0 / WAVE), xlo, ylo);
+        st2(tbox + 4 * (w0 / WAVE) + 2, xhi, yhi);
+      }
     }
   }
   SP_T(spb);
@@ -949,8 +971,12 @@ __device__ __forceinline__ void plan_emit(const d2d_state &s, const d2d_plan &p,
 // as a called function in the persistent loop, the common path does not pay the search's register saves.
 // `w_head_out` (optional): where the trajectory is kept, the head waypoint plan_emit stored (x, y, vx, vy), wave-uniform -- the
 // act phase of the persistent loop takes it from there instead of reading the planner's result back from memory.
+// `walls_ok` (optional; the persistent loop's own flag of this env): in = every remaining waypoint passed replan_check's wall test
+// at the step before AND nothing but this step's rays has written the explored map since (so only waypoints inside the cells the rays
+// can reach need the test again); out = the same for the next step.  Null: the test walks every waypoint (a stand-alone launch: the
+// host may have written the map between two calls).
 __device__ __forceinline__ bool plan_env_quick(const d2d_cfg &c, const d2d_state &s, const d2d_plan &p, int e, int lane, char *base,
-                                               double4 *w_head_out = nullptr) {
+                                               double4 *w_head_out = nullptr, int *walls_ok = nullptr) {
   const int N = c.N;
   TrkView T;
   SearchLds S;
@@ -1004,13 +1030,56 @@ __device__ __forceinline__ bool plan_env_quick(const d2d_cfg &c, const d2d_state
   {
     const int n = stored - head;
     bool bad = false;
-    for (int i0 = 0; i0 < n; i0 += WAVE) {
-      const int i = i0 + lane;
-      if (i < n) {
-        const double *w = traj + (size_t)(head + i) * 4;
+    // The walk, in chunks of 64 slots of the trajectory buffer.  A chunk is loaded only if its bounding box (d2d_plan.traj_box) says
+    // it can matter: it holds the head; or one of its waypoints can come within an active tracker's radius (the tracker's positions
+    // over the chunk's time span are a segment: box against box); or it can hold a waypoint on a cell the explored map has gained
+    // since the last full test -- inside a persistent launch only this step's rays write that map, within `reach` cells of the
+    // drone's cell.  Everything a box excludes is excluded exactly; the per-waypoint tests below are the reference's.
+    const int c_lo = head >> 6, c_hi = n > 0 ? (stored - 1) >> 6 : c_lo - 1;
+    const double *tbox = traj_boxes(p, e);
+    const bool chunked = tbox != nullptr && c_hi - c_lo < 64 && c_hi - c_lo >= D2D_TRAJ_PRUNE_CHUNKS;  // (short trajectories: as they are)
+    // (the swept value is uint8: beyond 2 560 waypoints it wraps to 0 and a waypoint skips the wall test for ten steps -- such a
+    // trajectory takes the full walk)
+    const bool walls_known = walls_ok != nullptr && *walls_ok != 0 && n < 2560;
+    unsigned long long cmask = 0ull;
+    bool walls_full = true;
+    if (__builtin_expect(chunked && n > 0, 0)) {
+      const double2 dpos = ld2(s.drone + (size_t)e * D2D_DF);  // the pose this step's rays were cast from (the control stage comes later)
+      bool need = false;
+      if (c_lo + lane <= c_hi) {
+        const int cc = c_lo + lane;
+        const double2 lo = ld2(tbox + 4 * cc), hi = ld2(tbox + 4 * cc + 2);
+        need = cc == c_lo;
+        if (!walls_known) {
+          need = true;
+        } else {
+          const int reach = (int)((c.depth + 1.5 * (c.scale - 1.0)) / c.scale) + 2;  // Geom.reach: the cells a ray can travel
+          const int ocx = cell_fast(dpos.x, c.scale, inv_scale), ocy = cell_fast(dpos.y, c.scale, inv_scale);
+          const double wx0 = (double)(ocx - reach) * c.scale, wx1 = (double)(ocx + reach + 1) * c.scale;
+          const double wy0 = (double)(ocy - reach) * c.scale, wy1 = (double)(ocy + reach + 1) * c.scale;
+          need = need | ((hi.x >= wx0) & (lo.x < wx1) & (hi.y >= wy0) & (lo.y < wy1));
+        }
+        const int a_lo = max(cc << 6, head), a_hi = min((cc << 6) + 63, stored - 1);
+        const double t_lo = (double)(a_lo - head) * c.dt, t_hi = (double)(a_hi - head) * c.dt;
+        for (int q = 0; q < nact; ++q) {
+          // estimate_pos(t) = m + t v is monotone in t on each axis: its values over the chunk lie between those at the two ends
+          const double mxq = T.mx[q], myq = T.my[q], vxq = T.vx[q], vyq = T.vy[q];
+          const double ex0 = mxq + t_lo * vxq, ex1 = mxq + t_hi * vxq, ey0 = myq + t_lo * vyq, ey1 = myq + t_hi * vyq;
+          const double rad = sqrt(T.lim[q]) * (1.0 + 1e-9) + 1e-9;   // d.d <= lim needs |dx| <= sqrt(lim) and |dy| <= sqrt(lim)
+          const double exl = fmin(ex0, ex1), exh = fmax(ex0, ex1), eyl = fmin(ey0, ey1), eyh = fmax(ey0, ey1);
+          need = need | ((hi.x + rad >= exl) & (lo.x - rad <= exh) & (hi.y + rad >= eyl) & (lo.y - rad <= eyh));
+        }
+      }
+      cmask = __ballot(need);
+      walls_full = !walls_known;
+    }
+    auto visit = [&](int a, bool first) {
+      if (a >= head && a < stored) {
+        const int i = a - head;
+        const double *w = traj + (size_t)a * 4;
         const double2 wxy = ld2(w), wv = ld2(w + 2);  // (x, y), (vx, vy)
         const double4 w4 = make_double4(wxy.x, wxy.y, wv.x, wv.y);
-        if (i0 == 0) w_first = w4;
+        if (first) w_first = w4;
         const double wx = w4.x, wy = w4.y;
         const double ti = (double)i * c.dt;
         const int ci = cell_fast(wx, c.scale, inv_scale), cj = cell_fast(wy, c.scale, inv_scale);
@@ -1032,8 +1101,23 @@ __device__ __forceinline__ bool plan_env_quick(const d2d_cfg &c, const d2d_state
           }
         }
       }
+    };
+    if (__builtin_expect(chunked, 0)) {
+      for (unsigned long long m = cmask; m; m &= m - 1ull) {
+        const int cc = c_lo + __ffsll((long long)m) - 1;
+        visit((cc << 6) + lane, cc == c_lo);
+      }
+    } else {
+      for (int a0 = head; a0 < stored; a0 += WAVE) visit(a0 + lane, a0 == head);   // (lane 0 of the first pass holds the head)
     }
-    if (__any(bad)) head = stored = 0;
+    // chunked: the head waypoint sits in lane head % 64 of the first chunk, plan_emit takes it from lane 0
+    if (__builtin_expect(chunked && n > 0, 0)) {
+      const int hl = head & 63;
+      w_first = make_double4(readlane_f64(w_first.x, hl), readlane_f64(w_first.y, hl), readlane_f64(w_first.z, hl), readlane_f64(w_first.w, hl));
+    }
+    const bool replan = __any(bad);
+    if (replan) head = stored = 0;
+    if (walls_ok) *walls_ok = (!replan && n > 0 && (walls_full || walls_known)) ? 1 : 0;
   }
   if (stored - head == 0) {  // Primitive.plan has to search: the trackers (and their count) wait in LDS
     // ... with the limit of Planner.is_free in the one limit plane (traj_planner.py:58: drone_radius + radius + 5 + var_cam, as
@@ -1387,13 +1471,38 @@ __device__ __forceinline__ void gaze_env(const d2d_cfg &c, const d2d_state &s, c
   // ---- v_i: the swept map inside the box (last write wins = largest waypoint index), :88-90 ----
   for (int q = lane; q < g.ncell; q += WAVE) swi[q] = -1;
   wave_sync_lds();
-  for (int i0 = 0; i0 < n; i0 += WAVE) {
-    const int i = i0 + lane;
-    if (i < n) {
-      const double *w = traj + (size_t)(head + i) * 4;
-      const int ci = cell_fast(w[0], c.scale, inv_scale), cj = cell_fast(w[1], c.scale, inv_scale);
-      const int r = ci - bi, cc = cj - bj;
-      if (ci >= 0 && ci < W && cj >= 0 && cj < H && r >= 0 && r < g.bbn && cc >= 0 && cc < g.bbn) atomicMax(&swi[r * g.bbn + cc], i);
+  {
+    // Only waypoints whose cell lies in the box count.  The trajectory is walked in chunks of 64 slots; a chunk whose bounding box
+    // (d2d_plan.traj_box, written with the trajectory) does not reach into the box's pixel range holds none and is not loaded: on a
+    // 6400 px map the remaining trajectory is up to 1 800 waypoints, the box holds the next few dozen.
+    const int c_lo = head >> 6, c_hi = (stored - 1) >> 6;
+    const double *tbox = traj_boxes(p, e);
+    unsigned long long cmask = 0ull;
+    // (short trajectories -- the 500 px maps: a few chunks -- are walked as they are: looking at the boxes costs what it saves)
+    const bool chunked = tbox != nullptr && c_hi - c_lo < 64 && c_hi - c_lo >= D2D_TRAJ_PRUNE_CHUNKS;
+    if (__builtin_expect(chunked, 0)) {
+      bool need = false;
+      if (c_lo + lane <= c_hi) {
+        const double2 lo = ld2(tbox + 4 * (c_lo + lane)), hi = ld2(tbox + 4 * (c_lo + lane) + 2);
+        const double bx0 = (double)bi * c.scale, bx1 = (double)(bi + g.bbn) * c.scale;
+        const double by0 = (double)bj * c.scale, by1 = (double)(bj + g.bbn) * c.scale;
+        need = (hi.x >= bx0) & (lo.x < bx1) & (hi.y >= by0) & (lo.y < by1);   // bi <= floor(x / scale) < bi + bbn for some waypoint
+      }
+      cmask = __ballot(need);
+    }
+    auto visit = [&](int a) {  // slot a of the trajectory buffer
+      if (a >= head && a < stored) {
+        const int i = a - head;
+        const double2 wxy = ld2(traj + (size_t)a * 4);
+        const int ci = cell_fast(wxy.x, c.scale, inv_scale), cj = cell_fast(wxy.y, c.scale, inv_scale);
+        const int r = ci - bi, cc = cj - bj;
+        if (ci >= 0 && ci < W && cj >= 0 && cj < H && r >= 0 && r < g.bbn && cc >= 0 && cc < g.bbn) atomicMax(&swi[r * g.bbn + cc], i);
+      }
+    };
+    if (__builtin_expect(chunked, 0)) {
+      for (unsigned long long m = cmask; m; m &= m - 1ull) visit(((c_lo + __ffsll((long long)m) - 1) << 6) + lane);
+    } else {
+      for (int a0 = head; a0 < stored; a0 += WAVE) visit(a0 + lane);
     }
   }
   wave_sync_global();  // LDS hand-off of the swept map AND the seen map the lanes wrote above

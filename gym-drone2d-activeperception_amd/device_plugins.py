@@ -236,7 +236,8 @@ class PluginState:
         self.tables = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in tb.items()}
         f64, i32, u8 = torch.float64, torch.int32, torch.uint8
         z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)
-        self.t = dict(traj=z((B, sc['traj_cap'], 4), f64), traj_hdr=z((B, 2), i32), trk_radius=z((B, max(N, 1)), f64),
+        self.t = dict(traj=z((B, sc['traj_cap'], 4), f64), traj_hdr=z((B, 2), i32), traj_box=z((B, (sc['traj_cap'] + 63) // 64, 4), f64),
+                      trk_radius=z((B, max(N, 1)), f64),
                       trk_prev=z((B, max(N, 1)), u8), trk_lim=z((B, max(N, 1)), f64), seen_step=z((B, cfg.W, cfg.H), i32),
                       nodes=z((B, sc['node_cap'], A.NODE_F), f64), hash=z((B, sc['hash_cap']), i32),
                       launch_args=z((A.LAUNCH_ARGS_BYTES,), u8), plan_stat=z((B, 4), i32))

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define D2D_ABI_VERSION 7
+#define D2D_ABI_VERSION 8
 
 /* grid cell codes, utils.py:11-16 */
 #define D2D_UNEXPLORED 0
@@ -265,6 +265,13 @@ typedef struct d2d_plan {
   /* ---- per-env plugin state (read + written) ---- */
   double D2D_AS *traj;         /* [B][traj_cap][4] planner.trajectory: position(2), velocity(2); accelerations are 0 */
   int32_t D2D_AS *traj_hdr;    /* [B][2] index of the head waypoint, number of waypoints stored (len = stored - head) */
+  double D2D_AS *traj_box;     /* [B][ceil(traj_cap / 64)][4] (ABI 8) or NULL: (xmin, ymin, xmax, ymax) of the waypoints stored in slots
+                           [64 c, 64 c + 64) of `traj`, written by the planner stage with every trajectory it stores.  Oxford's swept map
+                           and replan_check read every REMAINING waypoint at every step (up to 1 800 x 32 B on a 6400 px map); with the
+                           boxes they load only the 64-waypoint chunks that can matter -- those that reach into the view box, come
+                           within a tracker's safety radius, or cross the cells this step's rays wrote -- and skip the rest, exactly
+                           (a box is a bound, never an estimate).  NULL: every stage walks the whole trajectory.  Library-private
+                           contents (the oracle ignores the field) */
   double D2D_AS *trk_radius;   /* [B][N] drone.trackers[k].radius (envs/drone_v2.py:46; back to agent_radius on archive) */
   uint8_t D2D_AS *trk_prev;    /* [B][N] tracker.active as the planner stage last saw it (detects the archive) */
   double D2D_AS *trk_lim;      /* [B][N] cache kept by the library: the largest s with sqrt(s) <= drone_radius + trk_radius, i.e.

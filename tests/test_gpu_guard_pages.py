@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 PAGE = 2 << 20
 ENV_FIELDS = ('agents', 'dyn_prev', 'gt', 'dmap', 'drone', 'target', 'counters', 'active', 'kf', 'kf_len', 'hit', 'newly', 'flags',
               'obs_local', 'obs_yaw', 'action', 'wp')
-PLUGIN_FIELDS = ('traj_hdr', 'traj', 'trk_radius', 'trk_prev', 'seen_step', 'plan_stat')
+PLUGIN_FIELDS = ('traj_hdr', 'traj', 'traj_box', 'trk_radius', 'trk_prev', 'seen_step', 'plan_stat')
 
 DEFAULT = dict(agent_number=10, agent_radius=15, agent_max_speed=20)
 CASES = [
@@ -30,6 +30,7 @@ CASES = [
     ('nodes', 'plugins', DEFAULT),
     ('hash', 'plugins', DEFAULT),
     ('traj', 'plugins', DEFAULT),
+    ('traj_box', 'plugins', DEFAULT),                                                     # 992 B per env: 65536 envs
     ('seen_step', 'plugins', dict(agent_number=10, agent_radius=15, agent_max_speed=20, map_size=[640, 320], init_pos=[50, 50],
                                   target_list=[[580, 260]])),                             # 64 x 32 cells: the generic kernels
     ('gt', 'state', dict(agent_number=10, agent_radius=15, agent_max_speed=20, map_size=[640, 320], init_pos=[50, 50],

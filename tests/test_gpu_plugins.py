@@ -93,6 +93,10 @@ CASES = [
     # than 4096 cells (round 3 refused it with -4)
     dict(B=4, T=40, chunk=8, agent_number=12, agent_radius=12, agent_max_speed=30, map_id=33, map_size=[1000, 1000],
          drone_view_depth=150, drone_view_range=100, init_pos=[300, 300], target_list=[[800, 800]]),
+    # 2000 x 1600 px with pillars and fast agents: trajectories of many hundred waypoints, so the gaze stage and replan_check walk them
+    # through the chunk boxes (d2d_plan.traj_box) -- walls that come into view on the way (replans), trackers crossing far chunks
+    dict(B=6, T=240, chunk=16, agent_number=30, agent_radius=12, agent_max_speed=60, map_id=51, map_size=[2000, 1600],
+         pillar_number=9, init_pos=[120, 120], target_list=[[1880, 1480], [120, 1480]]),
     # 40 x 30 = 1200 cells: a perfect tree of 16 blocks (half the butterfly's lanes hold +0.0)
     dict(B=6, T=80, chunk=8, agent_number=6, agent_radius=10, agent_max_speed=20, map_id=22, map_size=[400, 300],
          init_pos=[50, 50], target_list=[[340, 240], [60, 240]]),
@@ -334,7 +338,7 @@ def test_config5_closed_loop_at_shard_scale(pkg, hip):
             assert bool((xs.view(xs.shape[0] // 4, 4, *x.shape[1:]) == y.unsqueeze(0)).all()), f'{name}: envs {c0}..'
     for name in FIELDS + ('action', 'plan_ok', 'wp_valid', 'wp'):
         same(big.state.t[name], small.state.t[name], name)
-    for name in PLUGIN_FIELDS + ('traj', 'plan_stat'):
+    for name in PLUGIN_FIELDS + ('traj', 'traj_box', 'plan_stat'):
         same(big.plugins.t[name], small.plugins.t[name], name)
     assert int(small.plugins.t['plan_stat'][:, 0].sum()) >= 4 and int(small.state.active.sum()) > 0   # searches ran, trackers are active
     assert int(big.plugins.t['plan_stat'][:, 3].sum()) == 0
