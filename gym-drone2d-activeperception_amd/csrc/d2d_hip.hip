@@ -201,6 +201,11 @@ __host__ __device__ inline Geom make_geom(const d2d_cfg &c, int wpb, int ncap_fi
   if (g.ncap < 4) g.ncap = 4;
   if (ncap_fixed) g.ncap = ncap_fixed;
   g.ccap = g.ncap < 64 ? g.ncap : 64;
+  // The whole-grid kernel for 17-40 agents addresses its candidates through a 32-bit mask anyway: 32 candidate slots instead of 40
+  // bring its wave to 8 176 B of LDS -- FIVE 4-wave workgroups per CU instead of four (its 93 VGPRs since the four-lane Kalman stage
+  // allow five waves per SIMD); an env with 33-40 candidates inside the cone tests every agent at every sample, as one with more
+  // than `ccap` always did.
+  if (full && g.ccap > 32) g.ccap = 32;
   g.reach = (int)((c.depth + 1.5 * (c.scale - 1.0)) / c.scale) + 2;
   g.ws = 2 * g.reach + 1;
   g.wdw = (g.ws * g.ws + 3) / 4;   // dwords of the window tile

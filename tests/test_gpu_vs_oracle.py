@@ -404,6 +404,43 @@ def test_many_agent_raycast_candidates_at_the_cone_edges(pkg, hip, oracle):
     assert int(ref.state.hit.sum(1).min()) >= 6
 
 
+def test_crowd_of_forty_in_the_whole_grid_kernel(pkg, hip, oracle):
+    """40 agents on the default geometry take the whole-grid kernel for 17-40 agents, whose candidate list holds 32 (Geom.ccap: five
+    workgroups per CU instead of four): with all 40 inside the cone of the rays -- more candidates than the list holds -- every
+    sample tests every agent, as the reference does; with 33 of them just the same.  Hit masks and every field equal the oracle's."""
+    from drone2d_amd import _abi as A
+    B, N = 12, 40
+    dev, ref = _pair(pkg, hip, oracle, B, agent_number=N, agent_radius=5, agent_max_speed=5, map_id=23, init_pos=[250, 250], drone_max_speed=40)
+    assert dev.cfg.N == N and dev.cfg.W == 50
+    fov = np.radians(dev.params.drone_view_range)
+    ag = ref.state.agents.clone()
+    yaw = torch.tensor([(e * 31.0) % 360 for e in range(B)], dtype=torch.float64)
+    for e in range(B):
+        pa = 2 * np.pi - np.radians(float(yaw[e]))
+        inside = N if e % 2 == 0 else 33                       # the other 7 stand behind the drone
+        for k in range(N):
+            if k < inside:
+                a = pa + (k % 10 - 4.5) / 10.0 * fov * 0.85
+                d = 24.0 + 14.0 * (k // 10) + 0.4 * (e % 5)
+            else:
+                a = pa + np.pi + 0.1 * (k - inside)
+                d = 60.0
+            ag[e, A.A_PX, k] = 250.0 + d * np.cos(a)
+            ag[e, A.A_PY, k] = 250.0 + d * np.sin(a)
+    ag[:, A.A_VX] = 0.0
+    ag[:, A.A_VY] = 0.0
+    for env in (dev, ref):
+        env.state.agents.copy_(ag)
+        env.state.drone[:, A.D_YAW] = yaw.to(env.state.drone.device)
+    rng = np.random.RandomState(9)
+    for t in range(6):
+        a = rng.choice([-0.5, 0.0, 0.5], B)
+        dev.step(a)
+        ref.step(a)
+        _assert_same(dev, ref, f'crowd of forty step {t + 1}')
+    assert int(ref.state.hit.sum(1).min()) >= 5
+
+
 @pytest.mark.parametrize('radius,speed', [(12, 60), (25, 40)])
 def test_two_phase_dynamic_grid_with_packed_agents(pkg, hip, oracle, radius, speed):
     """Grids above 256 x 256 cells update the dynamic cells in two phases (csrc dyn_apply<1> / <2>: every agent clears what its
