@@ -1117,7 +1117,9 @@ __device__ __forceinline__ bool plan_env_quick(const d2d_cfg &c, const d2d_state
     }
     const bool replan = __any(bad);
     if (replan) head = stored = 0;
-    if (walls_ok) *walls_ok = (!replan && n > 0 && (walls_full || walls_known)) ? 1 : 0;
+    // (n < 2560: every waypoint the NEXT step tests -- one index lower -- then had a non-zero swept value at this step too, i.e. was
+    // tested now; a longer trajectory holds waypoints whose uint8 value has wrapped to 0)
+    if (walls_ok) *walls_ok = (!replan && n > 0 && n < 2560 && (walls_full || walls_known)) ? 1 : 0;
   }
   if (stored - head == 0) {  // Primitive.plan has to search: the trackers (and their count) wait in LDS
     // ... with the limit of Planner.is_free in the one limit plane (traj_planner.py:58: drone_radius + radius + 5 + var_cam, as
@@ -1322,20 +1324,11 @@ __device__ __forceinline__ void gaze_env(const d2d_cfg &c, const d2d_state &s, c
   int steps = s.counters[(size_t)e * D2D_CF + D2D_C_STEPS];
   int head = 0, stored = 0;
   double ys_l = 0.0, tob_l = 0.0;  // lane a < n_yaw: yaw_space[a]; lane < D2D_TOBS_LDS: its entry of the table of times
-  int pw_l[4] = {0, 0, 0, 0}, pt_l[4] = {0, 0, 0, 0};
   if (oxford) {
     head = hdr[0];
     stored = hdr[1];
     ys_l = p.yaw_space[min(lane, max(p.n_yaw, 1) - 1)];
     tob_l = p.tobs_tab[min(lane, p.tobs_len - 1)];
-    if (!g.sparse) {
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int k = lane + u * WAVE;
-        pw_l[u] = p.pw_leaf[min(k, 4 * p.pw_nleaf - 1)];
-        pt_l[u] = p.pw_tree[min(k, p.pw_ntree - 1)];
-      }
-    }
   }
   if (was_done != 0) {
     reset_env(c, s, init, (size_t)e, lane);
@@ -1379,18 +1372,9 @@ __device__ __forceinline__ void gaze_env(const d2d_cfg &c, const d2d_state &s, c
   // the head of the trajectory (the point the candidates look from), requested now, used after the seen pass
   const double *__restrict__ traj = p.traj + (size_t)e * p.traj_cap * 4;
   const double2 hxy = *(const double2 *)(traj + (size_t)(n > 0 ? head : 0) * 4);
-  // the table head (the entries below 1: reward = the value itself) and the pairwise plan (a few hundred bytes) into LDS
+  // the table head (the entries below 1: reward = the value itself) into LDS (the pairwise plan -- a few hundred bytes -- only where
+  // the exact sums run: below, behind the quick decision)
   if (lane < D2D_TOBS_LDS) tobl[lane] = tob_l;
-  if (!g.sparse) {
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int k = lane + u * WAVE;
-      if (k < 4 * p.pw_nleaf) pwl[k] = pw_l[u];
-      if (k < p.pw_ntree) pwp[k] = pt_l[u];
-    }
-    for (int k = lane + 4 * WAVE; k < 4 * p.pw_nleaf; k += WAVE) pwl[k] = p.pw_leaf[k];  // (plans beyond 256 entries: none at the
-    for (int k = lane + 4 * WAVE; k < p.pw_ntree; k += WAVE) pwp[k] = p.pw_tree[k];       //  dense path's 4096-cell limit)
-  }
   const FastDiv fdb(g.bbn);
   // shortcut of view_cell: only for cones narrower than 180 degrees whose edge is well inside (0, 1); cos(half_fov)
   // is the double in the middle of the host's arccos window
@@ -1524,7 +1508,6 @@ __device__ __forceinline__ void gaze_env(const d2d_cfg &c, const d2d_state &s, c
     wide2 = cwd * cwd;
   }
   for (int k = lane; k < (g.ncell + 3) / 4; k += WAVE) ((unsigned int *)cm)[k] = 0u;  // no view bits anywhere else in the box
-  for (int k = lane; k < g.ncell; k += WAVE) rew[k] = 0.0;  // (the sums multiply by the view bit: no stale NaN / inf of another phase)
   int nlive = 0;
   {
     CellBox b;
@@ -1570,6 +1553,7 @@ __device__ __forceinline__ void gaze_env(const d2d_cfg &c, const d2d_state &s, c
 #ifndef D2D_GAZE_EXACT_ONLY
   double qa[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};  // this lane's part of every candidate's sum, in ANY order (the quick decision below)
 #endif
+  bool any_hot = false;  // this lane has met a cell that adds a non-zero term to some candidate's sum
   for (int l0 = 0; l0 < nlive; l0 += 4 * WAVE) {
     // four live cells per lane: their seen-map entries are fetched together, then their table rows, then the arithmetic
     int qq[4], sn[4];
@@ -1592,7 +1576,6 @@ __device__ __forceinline__ void gaze_env(const d2d_cfg &c, const d2d_state &s, c
 #pragma unroll
       for (int u = 0; u < 4; ++u) tobs[u] = sn[u] > 0 ? p.tobs_tab[call - min(sn[u], call)] : p.tobs_tab[p.tobs_len + call];
     }
-    unsigned int hr0 = 0, hr1 = 0, hc0 = 0, hc1 = 0;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       if (l0 + u * WAVE + lane < nlive) {
@@ -1654,18 +1637,8 @@ __device__ __forceinline__ void gaze_env(const d2d_cfg &c, const d2d_state &s, c
           }
         }
 #endif
-        const unsigned int hb = hot ? 1u : 0u;
-        hr0 |= r < 32 ? hb << (r & 31) : 0u;
-        hr1 |= r < 32 ? 0u : hb << (r & 31);
-        hc0 |= cc < 32 ? hb << (cc & 31) : 0u;
-        hc1 |= cc < 32 ? 0u : hb << (cc & 31);
+        any_hot = any_hot | hot;
       }
-    }
-    if ((hr0 | hr1) != 0u) {
-      if (hr0) atomicOr((unsigned int *)&rng[0], hr0);
-      if (hr1) atomicOr((unsigned int *)&rng[1], hr1);
-      if (hc0) atomicOr((unsigned int *)&rng[2], hc0);
-      if (hc1) atomicOr((unsigned int *)&rng[3], hc1);
     }
   }
   wave_sync_lds();
@@ -1682,9 +1655,7 @@ __device__ __forceinline__ void gaze_env(const d2d_cfg &c, const d2d_state &s, c
   // ~2000 of a (candidate, r) mapping whose lanes walk every slot of every block.
   GZ(4);  // rewards + candidate bits
   const FastDiv fdh(H);
-  const unsigned long long hrows = ((unsigned long long)(unsigned int)rng[1] << 32) | (unsigned int)rng[0];
-  const unsigned long long hcols = ((unsigned long long)(unsigned int)rng[3] << 32) | (unsigned int)rng[2];
-  if (hrows == 0ull) {  // every sum is 0: `max_reward < 0` never holds, the first candidate stays (yaw_planner.py:116-125)
+  if (!__any(any_hot)) {  // every sum is 0: `max_reward < 0` never holds, the first candidate stays (yaw_planner.py:116-125)
     if (lane == 0) act[e] = ys_l / p.yaw_rate_max;
     return;
   }
@@ -1727,6 +1698,29 @@ __device__ __forceinline__ void gaze_env(const d2d_cfg &c, const d2d_state &s, c
     wave_sync_lds();  // (the exact path re-uses `stk`)
   }
 #endif
+  // the box rows / columns that hold a non-zero term (`rng`, cleared above), from the view bits the reward pass left: only the exact
+  // sums need them, i.e. the few steps the quick decision does not settle
+  // the pairwise plan of the map (block table + addition tree) into LDS: needed from here on only
+  if (!g.sparse) {
+    for (int k = lane; k < 4 * p.pw_nleaf; k += WAVE) pwl[k] = p.pw_leaf[k];
+    for (int k = lane; k < p.pw_ntree; k += WAVE) pwp[k] = p.pw_tree[k];
+  }
+  // (and the reward plane outside the cells with a view bit is cleared: the sums multiply by the view bit, and 0 x a stale NaN / inf of
+  // another phase's bytes would not be 0)
+  for (int k = lane; k < g.ncell; k += WAVE)
+    if (cm[k] == 0) rew[k] = 0.0;
+  for (int l = lane; l < nlive; l += WAVE) {
+    const int q = swl[l];
+    if (cm[q] != 0) {
+      int r, cc;
+      fdb.divmod(q, r, cc);
+      atomicOr((unsigned int *)&rng[r < 32 ? 0 : 1], 1u << (r & 31));
+      atomicOr((unsigned int *)&rng[cc < 32 ? 2 : 3], 1u << (cc & 31));
+    }
+  }
+  wave_sync_lds();
+  const unsigned long long hrows = ((unsigned long long)(unsigned int)rng[1] << 32) | (unsigned int)rng[0];
+  const unsigned long long hcols = ((unsigned long long)(unsigned int)rng[3] << 32) | (unsigned int)rng[2];
   // rows / columns of the grid that hold a non-zero term (they lie inside the box and inside the map)
   const int row_lo = bi + __ffsll((long long)hrows) - 1, row_hi = bi + 63 - __clzll((long long)hrows);
   const int jlo = bj + __ffsll((long long)hcols) - 1, jhi = bj + 64 - __clzll((long long)hcols);
