@@ -1323,11 +1323,11 @@ __device__ __forceinline__ void gaze_env(const d2d_cfg &c, const d2d_state &s, c
   double x0 = dr[D2D_D_X], y0 = dr[D2D_D_Y], yaw = dr[D2D_D_YAW];
   int steps = s.counters[(size_t)e * D2D_CF + D2D_C_STEPS];
   int head = 0, stored = 0;
-  double ys_l = 0.0, tob_l = 0.0;  // lane a < n_yaw: yaw_space[a]; lane < D2D_TOBS_LDS: its entry of the table of times
+  double ys_l = 0.0, tob_l = 0.0;  // lane a < n_yaw (and a + 8, a + 16 ...): yaw_space[a]; lane < D2D_TOBS_LDS: its entry of the table of times
   if (oxford) {
     head = hdr[0];
     stored = hdr[1];
-    ys_l = p.yaw_space[min(lane, max(p.n_yaw, 1) - 1)];
+    ys_l = p.yaw_space[min(lane & 7, max(p.n_yaw, 1) - 1)];  // (lanes 8..15 hold 0..7's again: the view directions' sines)
     tob_l = p.tobs_tab[min(lane, p.tobs_len - 1)];
   }
   if (was_done != 0) {
@@ -1386,6 +1386,7 @@ __device__ __forceinline__ void gaze_env(const d2d_cfg &c, const d2d_state &s, c
   }
   // ---- the seven view directions in one pass: lane a < n_yaw = candidate a, lane 7 = the current pose (:71, :114) ----
   double *vdir = stk;  // [8][2], free until the add stacks are used
+#ifdef D2D_SINCOS_TWO_PASS
   if (lane < 8) {
     double cyv = 0.0, syv = 0.0;
     if (lane < p.n_yaw || lane == 7) {
@@ -1397,6 +1398,21 @@ __device__ __forceinline__ void gaze_env(const d2d_cfg &c, const d2d_state &s, c
     vdir[2 * lane] = cyv;
     vdir[2 * lane + 1] = syv;
   }
+#else
+  // lanes 0..7 the cosines, lanes 8..15 the (negated) sines of the same eight angles: one walk through the sin / cos code for both
+  // (d2d_sin_or_cos: each lane does what d2d_cos / d2d_sin do for its argument, bit for bit)
+  if (lane < 16) {
+    const int a = lane & 7;
+    double v = 0.0;
+    if (a < p.n_yaw || a == 7) {
+      // Drone2D.__init__ takes `yaw % 360` for the candidates (utils.py:718); the drone's own yaw already is
+      const double ty = (a == 7) ? yaw : py_mod360(yaw + ys_l * c.dt);
+      const double r = d2d_sin_or_cos(ty * deg2rad, lane < 8);
+      v = lane < 8 ? r : -r;
+    }
+    vdir[2 * a + (lane >> 3)] = v;
+  }
+#endif
   // the largest yaw step of a candidate, degrees: a maximum over the lanes that hold the rates (exact in any order)
   double span_deg;
   {
@@ -2007,7 +2023,10 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK) void k_plan_reset(d2d_cfg c,
 __global__ void k_sincos(const double *in, double *so, double *co, long long n) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) {
-    so[i] = d2d_sin(in[i]);
-    co[i] = d2d_cos(in[i]);
+    // through the routine the gaze stage uses, with sines and cosines mixed among the lanes of a wave as they are there
+    const int odd = (int)(threadIdx.x & 1);
+    const double first = d2d_sin_or_cos(in[i], odd), second = d2d_sin_or_cos(in[i], odd ^ 1);
+    so[i] = odd ? second : first;
+    co[i] = odd ? first : second;
   }
 }

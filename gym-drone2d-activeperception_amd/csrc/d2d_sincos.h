@@ -146,4 +146,44 @@ D2D_SINCOS_QUAL double d2d_cos(double x) {
   return d2d_do_sincos(a, da, n + 1);
 }
 
+/* sin x (is_cos == 0) or cos x (is_cos != 0) in ONE pass through the routines above: d2d_sin and d2d_cos both end in
+ * do_sin or do_cos of a reduced argument (a, da) -- which of the two, with which (a, da) and which sign fix-up, is what differs
+ * between them and between the ranges of |x|.  A SIMD caller that needs both the sine and the cosine of its angles gives the two to
+ * different lanes and pays for one reduction, one do_sin and one do_cos instead of two of each (the gaze stage: lanes 0..7 the
+ * cosines, 8..15 the sines of its eight view directions).  Every lane performs exactly the operations d2d_sin / d2d_cos perform for
+ * its argument: the results are bit-identical (tests/test_sincos.py and the device hook run THIS function against libm). */
+D2D_SINCOS_QUAL double d2d_sin_or_cos(double x, int is_cos) {
+  const double hp0 = 0x1.921fb54442d18p+0, hp1 = 0x1.1a62633145c07p-54;
+  const double w = __builtin_fabs(x);
+  if (w < (is_cos ? 0x1p-27 : 0x1p-26)) return is_cos ? 1.0 : x;
+  if (!(w < 0x1.921fbp+26)) return __builtin_nan(""); /* 105414350 */
+  /* what to evaluate: do_cos (use_cos) or do_sin of (a, da); then copysign(result, x) (sign_x) or negation (neg) */
+  double a, da;
+  int use_cos, sign_x = 0, neg = 0;
+  if (w < 0x1.b6p-1) { /* 0.85546875 */
+    a = x;
+    da = 0.0;
+    use_cos = is_cos;
+  } else if (w < 0x1.368fdp+1) { /* 2.426265 */
+    if (is_cos) {
+      const double y = hp0 - w;
+      a = y + hp1;
+      da = (y - a) + hp1;
+      use_cos = 0;
+    } else {
+      a = hp0 - w;
+      da = hp1;
+      use_cos = 1;
+      sign_x = 1;
+    }
+  } else {
+    const int n = d2d_reduce_sincos(x, &a, &da) + (is_cos ? 1 : 0);
+    use_cos = n & 1;
+    neg = n & 2;
+  }
+  double r = use_cos ? d2d_do_cos(a, da) : d2d_do_sin(a, da);
+  if (sign_x) r = __builtin_copysign(r, x);
+  return neg ? -r : r;
+}
+
 #endif /* D2D_SINCOS_H */

@@ -20,7 +20,7 @@ def sc_host(tmp_path_factory):
                            '-o', so, os.path.join(ROOT, 'tests', 'csrc', 'sincos_host.c'), '-lm'])
     lib = C.CDLL(so)
     out = {}
-    for name in ('sin', 'cos'):
+    for name in ('sin', 'cos', 'sin1', 'cos1'):
         fn = getattr(lib, f'd2d_{name}_host_array')
         fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
 
@@ -75,6 +75,13 @@ def test_sincos_restatement_is_bit_identical_to_libm(sc_host):
         assert np.array_equal(got[idx].view(np.int64), ref.view(np.int64)), name
         m = np.array([getattr(math, name)(float(v)) for v in x[:50000]])      # and Python's math module itself
         assert np.array_equal(got[:50000].view(np.int64), m.view(np.int64)), name
+        # d2d_sin_or_cos (what the gaze stage calls: sines and cosines in one pass) is the same function, bit for bit, everywhere
+        one = sc_host[name + '1'](x)
+        assert np.array_equal(one.view(np.int64), got.view(np.int64)), name
+    for v in (np.inf, -np.inf, np.nan, 2e8, -2e8):
+        for name in ('sin', 'cos'):
+            a, b = sc_host[name](np.array([v])), sc_host[name + '1'](np.array([v]))
+            assert np.isnan(a[0]) and np.isnan(b[0])
 
 
 def test_radians_constant():
