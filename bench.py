@@ -334,6 +334,8 @@ def survivability_bench(args):
     algo_total = sum(r['algo_bytes_per_env_step'] * r['envs_per_launch'] * 240 for r in per_n)
     achieved = algo_total / t['device_s'] / 1e9
     dom = max(per_n, key=lambda r: r['device_s_two_streams'])
+    k = _pmc_entry('k_stages', {'workload': 'survivability'})       # tools/gpu_profile_surv.sh: bytes per env-step over the run's launches
+    traffic = k['hbm_bytes_per_env_step'] * t['env_steps'] if k and k.get('hbm_bytes_per_env_step') else None
     line = {'metric': 'env-steps/sec (survivability table: glob_survivability_calculator.py, NoMove / NoControl, drone pinned per start cell)',
             'value': t['env_steps'] / t['device_s'], 'unit': 'env-steps/s', 'n_gpus': 1, 'steps': 240, 'warmup': 0,
             'ms_per_step': t['device_s'] * 1e3 / (240 * len(t['batches'])), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
@@ -345,7 +347,12 @@ def survivability_bench(args):
             'end_to_end': {'wall_s': wall, 'host_build_s': t['build_s'], 'device_s': t['device_s'], 'host_post_s': t['post_s'],
                            'env_steps_per_s_wall': t['env_steps'] / wall},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                         'traffic': None, 'kernel': 'k_stages (fused Drone2DEnv2.step; d2d_rollout = one launch per step per stream)',
+                         'traffic': traffic, 'traffic_raw': k['hbm_bytes_per_env_step_raw'] * t['env_steps'] if traffic else None,
+                         'traffic_source': (f'{PMC_FILE} [k_stages, survivability]: {k["hbm_bytes_per_env_step"]:.0f} B per env-step corrected '
+                                            f'({k["hbm_bytes_per_env_step_raw"]:.0f} as counted) x {t["env_steps"]} env-steps of the table '
+                                            f'(like `achieved`: the whole table, not one launch)') if traffic
+                                           else f'{PMC_FILE} holds no PMC pass of this workload',
+                         'kernel': 'k_stages (fused Drone2DEnv2.step; d2d_rollout = one launch per step per stream)',
                          'note': 'achieved = algorithmic bytes (SURVEY 8(d), per agent count) of all launches / device time of the table; '
                                  'per agent count: the kernel\'s average launch time on one stream (synchronised wall clock around the 240 queued launches)',
                          'dominant_batch': dom, 'per_agent_count': per_n},
