@@ -170,6 +170,16 @@ class Clock:
             self.torch.cuda.synchronize(self.device)
 
     def timed_us(self, fn):
+        import gc
+        on = gc.isenabled()
+        gc.disable()       # (as timeit does: a full collection of the interpreter's heap between two launches is ~10 ms of an empty queue)
+        try:
+            return self._timed_us(fn)
+        finally:
+            if on:
+                gc.enable()
+
+    def _timed_us(self, fn):
         if self.gpu:
             e0, e1 = self.torch.cuda.Event(enable_timing=True), self.torch.cuda.Event(enable_timing=True)
             e0.record(self.stream)
@@ -308,22 +318,37 @@ def survivability_bench(args):
     import torch
     import drone2d_amd as pkg
     from drone2d_amd import sweeps, _lib
+    maps = list(range(args.maps))
+    # the host's share first: the 27 x maps seeded worlds (the reference's __init__ per setting, pure Python), over --workers forked
+    # processes BEFORE this process touches the GPU (0 = one after the other, in-process)
+    b0 = time.perf_counter()
+    worlds = sweeps.survivability_worlds(map_ids=maps, workers=args.workers)
+    worlds_s = time.perf_counter() - b0
     hip = _lib.HipBackend('cuda:0')
     device = str(hip.device)                 # (a CPU backend injected by the tests' dry-run harness reports 'cpu')
-    maps = list(range(args.maps))
-    sweeps.survivability_table(map_ids=maps, device=device, backend=hip)         # warm-up: the same table once (modules loaded, the
-    #                                                                              side streams and the allocator's blocks exist)
+    sweeps.survivability_table(map_ids=maps, device=device, backend=hip, worlds=worlds)   # warm-up: the same table once (modules loaded,
+    #                                                                              the side streams and the allocator's blocks exist)
     t = {}
+    import gc
+    gc.collect()
+    gc.disable()           # (as timeit does: a full collection of the interpreter's heap is ~10 ms, a third of the table's device time)
     w0 = time.perf_counter()
-    table = sweeps.survivability_table(map_ids=maps, device=device, backend=hip, timings=t)
-    wall = time.perf_counter() - w0
+    table = sweeps.survivability_table(map_ids=maps, device=device, backend=hip, timings=t, worlds=worlds)
+    wall = worlds_s + time.perf_counter() - w0
+    order_n = [n for _ in maps for n in (10, 20, 30) for _ in range(9)]          # agent count of every setting, in the table's order
     # the kernel's own average launch time, per agent count, on ONE stream with HIP events (the rollout above runs two half-batches
     # on two free-running streams, whose launches overlap: its time / launches is not a kernel duration)
     per_n = []
     for rec in t['batches']:
         t1 = {}
-        sel = dict(map_ids=maps, agent_numbers=(rec['N'],), device=device, backend=hip, timings=t1, streams=1)
+        sel = dict(map_ids=maps, agent_numbers=(rec['N'],), device=device, backend=hip, timings=t1, streams=1,
+                   worlds=[w for w, n in zip(worlds, order_n) if n == rec['N']])
         sweeps.survivability_table(**sel)
+        first = t1['device_s']
+        t1.clear()                               # twice, the faster one kept: the first single-stream chain after the two-stream table
+        sweeps.survivability_table(**sel)        # has shown one-off stalls of several ms (stream teardown of the runs before)
+        if first < t1['device_s']:
+            t1['device_s'] = first
         env = t1['last_env']
         algo = algo_bytes(env.cfg, env.state.agent_unit)
         launch_us = t1['device_s'] * 1e6 / t1['launches']
@@ -331,6 +356,7 @@ def survivability_bench(args):
                       'algo_bytes_per_env_step': algo, 'achieved_GBs': algo * rec['envs'] / (launch_us * 1e-6) / 1e9,
                       'device_s_two_streams': rec['device_s'], 'device_s_one_stream': t1['device_s']})
         del t1['last_env']
+    gc.enable()
     algo_total = sum(r['algo_bytes_per_env_step'] * r['envs_per_launch'] * 240 for r in per_n)
     achieved = algo_total / t['device_s'] / 1e9
     dom = max(per_n, key=lambda r: r['device_s_two_streams'])
@@ -344,8 +370,10 @@ def survivability_bench(args):
                                    f'8 x 8 start cells x 240 steps = {t["env_steps"]} env-steps; one batch per agent count '
                                    f'({t["batches"][0]["envs"]} envs), two half-batches on two streams',
                        'name': 'survivability', 'table_shape': list(table.shape), 'collisions_recorded': int(table.sum())},
-            'end_to_end': {'wall_s': wall, 'host_build_s': t['build_s'], 'device_s': t['device_s'], 'host_post_s': t['post_s'],
-                           'env_steps_per_s_wall': t['env_steps'] / wall},
+            'end_to_end': {'wall_s': wall, 'host_worlds_s': worlds_s, 'host_worlds_workers': args.workers, 'host_build_s': t['build_s'],
+                           'device_s': t['device_s'], 'host_post_s': t['post_s'], 'env_steps_per_s_wall': t['env_steps'] / wall,
+                           'note': 'wall = the seeded worlds built on the host (host_worlds_s, over --workers processes) + the table call: '
+                                   'batches assembled and uploaded (host_build_s), the 240-step rollouts (device_s), flags unpacked (host_post_s)'},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'traffic': traffic, 'traffic_raw': k['hbm_bytes_per_env_step_raw'] * t['env_steps'] if traffic else None,
                          'traffic_source': (f'{PMC_FILE} [k_stages, survivability]: {k["hbm_bytes_per_env_step"]:.0f} B per env-step corrected '

@@ -37,6 +37,19 @@ def untile_grid(t, W, H, tile=TILE):
     return g[..., :W, :H].contiguous()
 
 
+def distinct_worlds(worlds):
+    """(the distinct dicts of the list in order of first appearance, the position of every entry among them): by identity, not by
+    content -- two equal worlds built separately stay two."""
+    seen, distinct, index = {}, [], []
+    for w in worlds:
+        k = seen.get(id(w))
+        if k is None:
+            k = seen[id(w)] = len(distinct)
+            distinct.append(w)
+        index.append(k)
+    return distinct, index
+
+
 def _spec(B, N, W, H, L, T, grid_tile=0):
     f64, i32, u8, f32 = torch.float64, torch.int32, torch.uint8, torch.float32
     gshape = (B, (-(-W // grid_tile)) * (-(-H // grid_tile)) * grid_tile * grid_tile) if grid_tile else (B, W, H)
@@ -96,18 +109,28 @@ class BatchState:
         self.t[name][envs] = g.to(self.device)
 
     def load_worlds(self, worlds):
-        """Fill the world fields from a list of host_init.init_world() dicts (one per env)."""
+        """Fill the world fields from a list of host_init.init_world() dicts (one per env).  A list that names the same dict many
+        times (a sweep's start cells on one seeded world, a bench batch tiled from fewer distinct worlds) is staged once per
+        distinct world and spread over the envs on the device."""
         B = self.cfg.B
         assert len(worlds) == B
+        distinct, index = distinct_worlds(worlds)
+        U = len(distinct)
+        idx = torch.as_tensor(index, dtype=torch.int64, device=self.device) if U < B else None
         for name in ('agents', 'agent_unit', 'dyn_prev', 'gt', 'dmap', 'drone', 'target', 'targets', 'counters'):
             # in slices of <= 256 MB of host staging: a config-5 shard is 32768 grids of 640 x 640 cells = 13.4 GB per field
-            per = max(1, int(np.asarray(worlds[0][name]).nbytes))
+            per = max(1, int(np.asarray(distinct[0][name]).nbytes))
             step = max(1, (256 << 20) // per)
-            for c0 in range(0, B, step):
-                arr = torch.from_numpy(np.stack([w[name] for w in worlds[c0:c0 + step]])).to(self.t[name].dtype)
+            dst = self.t[name] if idx is None else torch.empty((U,) + tuple(self.t[name].shape[1:]), dtype=self.t[name].dtype, device=self.device)
+            for c0 in range(0, U, step):
+                arr = torch.from_numpy(np.stack([w[name] for w in distinct[c0:c0 + step]])).to(self.t[name].dtype)
                 if name in ('gt', 'dmap') and self.cfg.grid_tile:
                     arr = tile_grid(arr, self.cfg.grid_tile)
-                self.t[name][c0:c0 + step].copy_(arr)
+                dst[c0:c0 + step].copy_(arr)
+            if idx is not None:
+                for c0 in range(0, B, step):                       # (the gather's temporary stays within the same 256 MB)
+                    self.t[name][c0:c0 + step] = dst[idx[c0:c0 + step]]
+                del dst
         self.t['active'].zero_()
         self._kf_defaults()
 

@@ -15,7 +15,7 @@ import numpy as np
 import torch
 
 from .params import Params
-from .vec_env import VecDrone2DEnv, build_worlds
+from .vec_env import VecDrone2DEnv, build_worlds, build_worlds_of
 
 
 def _params(index):
@@ -35,22 +35,23 @@ def start_cells(params, position_step=60):
     return xs, ys
 
 
-def survivability_batch(indices, position_step=60, T=24, device='cuda:0', backend=None, timings=None, streams=None):
+def survivability_batch(indices, position_step=60, T=24, device='cuda:0', backend=None, timings=None, streams=None, worlds=None):
     """Collision states of several settings that share agent_number (same N), one launch.
     Returns float64 [len(indices), len(x_range), len(y_range), n_steps] with 1 where the drone pinned at that
     start cell is in dynamic collision at that step (collision_flag == 2).
     `timings`: a dict that collects, per call, the seconds spent building the worlds on the host (`build_s`), in the T-step
     rollout on the device with everything resident (`device_s`, synchronised on both sides) and in the host post-processing
-    (`post_s`), with `env_steps` and `launches` (bench.py --workload survivability)."""
+    (`post_s`), with `env_steps` and `launches` (bench.py --workload survivability).
+    `worlds`: the seeded worlds of `indices`, one each, when the caller has built them already (survivability_worlds)."""
     import time
     t_build = time.perf_counter()
     plist = [_params(ix) for ix in indices]
     xs, ys = start_cells(plist[0], position_step)
     cells = [(x, y) for x in xs for y in ys]
     n_steps = len(np.arange(0, T, 0.1))
+    seeded = worlds if worlds is not None else [build_worlds(p, 1)[0] for p in plist]
     worlds, pins = [], []
-    for p in plist:
-        w = build_worlds(p, 1)[0]
+    for w in seeded:
         worlds += [w] * len(cells)             # every start cell begins from the same seeded world (env.reset())
         pins += cells
     env = VecDrone2DEnv(plist[0], len(worlds), device=device, backend=backend, planner='NoMove', worlds=worlds)
@@ -86,16 +87,32 @@ def survivability(index, position_step=60, T=24, device='cuda:0', backend=None):
     return survivability_batch([index], position_step, T, device, backend)[0]
 
 
+def _table_order(map_ids, agent_numbers, agent_sizes, agent_speeds):
+    return [dict(motion_profile='CVM', pillar_number=0, agent_number=n, agent_speed=v, agent_size=r, map_id=m)
+            for m in map_ids for (n, r, v) in itertools.product(agent_numbers, agent_sizes, agent_speeds)]
+
+
+def survivability_worlds(map_ids=range(20), agent_numbers=(10, 20, 30), agent_sizes=(5, 10, 15), agent_speeds=(20, 40, 60), workers=0):
+    """The seeded worlds of survivability_table's settings, in its order: the host's share of the table (pure Python, 1-4 ms each),
+    optionally over `workers` forked processes -- like vec_env.build_worlds, only BEFORE the process touches the GPU.  Hand the
+    list to survivability_table(worlds=...)."""
+    return build_worlds_of([_params(ix) for ix in _table_order(map_ids, agent_numbers, agent_sizes, agent_speeds)], workers=workers)
+
+
 def survivability_table(map_ids=range(20), agent_numbers=(10, 20, 30), agent_sizes=(5, 10, 15),
-                        agent_speeds=(20, 40, 60), position_step=60, T=24, device='cuda:0', backend=None, timings=None, streams=None):
+                        agent_speeds=(20, 40, 60), position_step=60, T=24, device='cuda:0', backend=None, timings=None, streams=None,
+                        worlds=None):
     """The array the reference saves as collision_states_*.npy (glob_survivability_calculator.py:44-57), in its
-    loop order: map_id outermost, then product(agent_num, agent_size, agent_vel)."""
-    order = [dict(motion_profile='CVM', pillar_number=0, agent_number=n, agent_speed=v, agent_size=r, map_id=m)
-             for m in map_ids for (n, r, v) in itertools.product(agent_numbers, agent_sizes, agent_speeds)]
+    loop order: map_id outermost, then product(agent_num, agent_size, agent_vel).  `worlds`: survivability_worlds() of the same
+    arguments (else the worlds are built here, one after the other)."""
+    order = _table_order(map_ids, agent_numbers, agent_sizes, agent_speeds)
+    if worlds is not None and len(worlds) != len(order):
+        raise ValueError(f'survivability_table: {len(worlds)} worlds for {len(order)} settings')
     result = [None] * len(order)
     for n in agent_numbers:                    # one batch per agent count (a batch shares N)
         sel = [i for i, ix in enumerate(order) if ix['agent_number'] == n]
-        got = survivability_batch([order[i] for i in sel], position_step, T, device, backend, timings, streams)
+        got = survivability_batch([order[i] for i in sel], position_step, T, device, backend, timings, streams,
+                                  worlds=None if worlds is None else [worlds[i] for i in sel])
         for i, g in zip(sel, got):
             result[i] = g
     return np.array(result)

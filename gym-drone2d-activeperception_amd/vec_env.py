@@ -42,6 +42,17 @@ def build_worlds(params, num_envs, env_offset=0, workers=0):
     return [_build_world(j) for j in jobs]
 
 
+def build_worlds_of(params_list, workers=0):
+    """One world per Params of the list (each with its own map_id and agent settings: the survivability sweep's 540 settings).
+    `workers` as in build_worlds: forked processes, only before the process touches the GPU."""
+    jobs = [(with_defaults(p), p.map_id) for p in params_list]
+    if workers and len(jobs) >= 64:
+        import multiprocessing as mp
+        with mp.get_context('fork').Pool(workers) as pool:
+            return pool.map(_build_world, jobs, chunksize=max(1, len(jobs) // (workers * 4)))
+    return [_build_world(j) for j in jobs]
+
+
 class VecDrone2DEnv:
     def __init__(self, params, num_envs, device='cuda:0', planner=None, env_offset=0, backend=None,
                  kf_enabled=True, worlds=None, device_plugins=False, gaze=None, grid_layout=None):
@@ -74,7 +85,12 @@ class VecDrone2DEnv:
                                         kf_enabled=kf_enabled, grid_tile=16 if grid_layout == 'tiled' else 0)
         self.state = BatchState(self.cfg, self.device)
         self.state.load_worlds(worlds)
-        self.tracker_radius = torch.from_numpy(np.stack([w['tracker_radius'] for w in worlds])) if worlds else None
+        if worlds:
+            from .state import distinct_worlds
+            distinct, index = distinct_worlds(worlds)
+            self.tracker_radius = torch.from_numpy(np.stack([w['tracker_radius'] for w in distinct]))[torch.as_tensor(index)]
+        else:
+            self.tracker_radius = None
         self.init_state = self.state.clone_world()
         self._st = self.state.struct()
         self._init_st = self.init_state.struct()

@@ -115,3 +115,37 @@ def test_noise_rows_continue_across_chunked_calls(pkg, oracle):
     parts.cfg.noise_row0 = 7
     with pytest.raises(Exception):
         parts.closed_loop(1, auto_reset=True)
+
+
+@pytest.mark.parametrize('layout', ['rowmajor', 'tiled'])
+def test_a_batch_that_repeats_worlds_loads_like_one_of_copies(pkg, oracle, layout):
+    """A world list that names the same dict many times (a sweep's start cells, a bench batch tiled from fewer worlds) is staged once
+    per distinct world and gathered on the device: every field equals the load of a list of separate copies, in both grid layouts;
+    and the batch steps like it."""
+    import copy
+    from drone2d_amd import vec_env
+    from drone2d_amd.state import distinct_worlds
+    p = pkg.Params(planner='NoMove', agent_number=7, agent_radius=10, agent_max_speed=20, map_id=3)
+    base = vec_env.build_worlds(p, 3)
+    order = [0, 2, 2, 1, 0, 0, 2, 1, 1, 0, 2]
+    shared = [base[i] for i in order]
+    copies = [copy.deepcopy(base[i]) for i in order]
+    d, ix = distinct_worlds(shared)
+    assert [id(w) for w in d] == [id(base[0]), id(base[2]), id(base[1])] and ix == [0, 1, 1, 2, 0, 0, 1, 2, 2, 0, 1]
+    assert len(distinct_worlds(copies)[0]) == len(order)          # by identity: separate copies stay separate
+    a = vec_env.VecDrone2DEnv(p, len(order), backend=oracle, worlds=shared, grid_layout=layout)
+    b = vec_env.VecDrone2DEnv(p, len(order), backend=oracle, worlds=copies, grid_layout=layout)
+    fields = ('agents', 'agent_unit', 'dyn_prev', 'gt', 'dmap', 'drone', 'target', 'targets', 'counters')
+    for name in fields:
+        assert torch.equal(a.state.t[name], b.state.t[name]), name
+    assert torch.equal(a.tracker_radius, b.tracker_radius)
+    for i, k in enumerate(order):
+        assert np.array_equal(a.state.logical('gt')[i].numpy(), base[k]['gt'])
+    if layout == 'tiled':               # (the oracle steps row-major grids only: the load is what this case checks)
+        return
+    acts = np.random.RandomState(1).uniform(-1, 1, (12, len(order)))
+    for t in range(12):
+        a.step(acts[t])
+        b.step(acts[t])
+    for name in fields + ('flags', 'hit', 'kf', 'active'):
+        assert torch.equal(a.state.t[name], b.state.t[name]), name
