@@ -326,8 +326,9 @@ def survivability_bench(args):
     worlds_s = time.perf_counter() - b0
     hip = _lib.HipBackend('cuda:0')
     device = str(hip.device)                 # (a CPU backend injected by the tests' dry-run harness reports 'cpu')
-    sweeps.survivability_table(map_ids=maps, device=device, backend=hip, worlds=worlds)   # warm-up: the same table once (modules loaded,
-    #                                                                              the side streams and the allocator's blocks exist)
+    if device != 'cpu':
+        sweeps.survivability_table(map_ids=maps, device=device, backend=hip, worlds=worlds)   # warm-up: the same table once (modules
+        #                                                                      loaded, the side streams and the allocator's blocks exist)
     t = {}
     import gc
     gc.collect()
